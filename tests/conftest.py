@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long-running CPU test")
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    from oracle import oracle as orc
+
+    orc.build()
+    return orc
+
+
+@pytest.fixture(scope="session")
+def ref(oracle_mod):
+    R = oracle_mod.ref_lib()
+    if R is None:
+        pytest.skip("oracle/_ref was never built (needs /root/reference in the dev container)")
+    return R
