@@ -1,0 +1,1022 @@
+// beam_search.hip -- MI355X (gfx950 / CDNA4) implementation of flatnav's batched k-NN search
+// and the C ABI declared in include/flatnav_hip.h.
+//
+// Reference path being replaced (paths relative to the reference repo):
+//   Index::search              include/flatnav/index/Index.h:387-409
+//   Index::initializeSearch    include/flatnav/index/Index.h:845-870
+//   Index::beamSearch          include/flatnav/index/Index.h:606-659
+//   Index::processCandidateNode include/flatnav/index/Index.h:661-707
+//   distance dispatch          include/flatnav/distances/{L2,IP}DistanceDispatcher.h
+//   VisitedSet                 include/flatnav/util/VisitedSetPool.h:16-50
+//   batched loop               python-bindings/src/flatnav/bindings.cpp:161-228
+//
+// Execution model: one 64-lane wavefront = one query at a time; a
+// persistent grid of query slots (as many as LDS lets stay resident) pulls query ids
+// from an atomic dispenser.  Per query, in LDS: the query vector, the two binary
+// heaps of the reference (moved with libstdc++'s exact algorithm, stl_exact.h), an
+// exact open-addressing visited set, and a 64-entry staging area.  Per hop the wave
+// loads one link row (M ids, coalesced), tests/marks all of them in the visited set
+// in parallel, gathers the unvisited neighbours' vectors with 16-byte loads (G lanes
+// per vector so each lane group reads whole 128-byte lines, PU*CU loads in flight per
+// lane), reduces the distances across lanes with DPP, then replays the reference's
+// sequential admission rule on the results.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <limits>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/flatnav_hip.h"
+#include "stl_exact.h"
+
+namespace {
+
+constexpr uint32_t EMPTY_ID = 0xFFFFFFFFu;
+constexpr int WAVE = 64;
+constexpr int PU = 4;  // vector "passes" whose loads are issued back to back before any use
+
+enum : int { ST_OK = 0, ST_CAND_OVERFLOW = 1 };
+
+struct SearchParams {
+  const uint8_t* vectors;   // [n_nodes][row_bytes]
+  const uint32_t* links;    // [n_nodes][M]
+  const int32_t* labels;    // [n_nodes]
+  const uint8_t* queries;   // [nq][dim] elements, dense
+  float* out_dist;          // [nq][K]
+  int32_t* out_labels;      // [nq][K]
+  int32_t* out_count;       // [nq] or null
+  uint64_t* out_ndist;      // [nq] or null
+  uint64_t* out_nhops;      // [nq] or null
+  uint32_t* dispenser;      // next query id
+  int32_t* status;          // sticky error flag for the whole launch
+  uint32_t* ovf_bitmap;     // [nslots][bitmap_words] visited-set spill (all zero between queries)
+  unsigned long long* cand_spill;  // [nslots][spill_entries]
+  uint64_t n_nodes;
+  uint32_t nq, M, dim, row_bytes, nchunks, q_chunks;
+  int K, B;
+  uint32_t n_scan, scan_step;
+  uint32_t vis_slots, vis_shift, vis_limit;
+  uint32_t cand_slots, spill_entries, bitmap_words;
+  uint32_t off_q, off_nbr, off_cand, off_vis, off_stage_ids, off_stage_d;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Heaps: 8-byte entries {float key | uint32 id} packed in one 64-bit LDS word.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long pack(fnv_stl::Entry e) {
+  return (unsigned long long)__float_as_uint(e.key) | ((unsigned long long)e.val << 32);
+}
+__device__ __forceinline__ fnv_stl::Entry unpack(unsigned long long v) {
+  fnv_stl::Entry e;
+  e.key = __uint_as_float((uint32_t)v);
+  e.val = (uint32_t)(v >> 32);
+  return e;
+}
+
+struct LdsHeap {
+  unsigned long long* p;
+  __device__ __forceinline__ fnv_stl::Entry get(int i) const { return unpack(p[i]); }
+  __device__ __forceinline__ void set(int i, fnv_stl::Entry e) { p[i] = pack(e); }
+};
+
+// Candidates heap: first `cap` entries in LDS, the rest in a per-slot HBM spill area.  Only lane 0
+// ever touches it, so plain program order keeps it coherent.
+struct CandHeap {
+  unsigned long long* p;
+  unsigned long long* spill;
+  int cap;
+  __device__ __forceinline__ fnv_stl::Entry get(int i) const { return unpack(i < cap ? p[i] : spill[i - cap]); }
+  __device__ __forceinline__ void set(int i, fnv_stl::Entry e) {
+    if (i < cap) p[i] = pack(e);
+    else spill[i - cap] = pack(e);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Cross-lane sums over aligned groups of G lanes (DPP inside a 16-lane row, bpermute above).
+// Every step adds the same two operands in both partner lanes, so all lanes of a group end with
+// bit-identical sums.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) {
+  return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
+}
+template <int G, typename A>
+__device__ __forceinline__ A group_sum(A v) {
+  v += dpp_mov<0xB1>(v);                       // quad_perm [1,0,3,2]  (lane ^ 1)
+  v += dpp_mov<0x4E>(v);                       // quad_perm [2,3,0,1]  (lane ^ 2)
+  if (G >= 8) v += dpp_mov<0x141>(v);          // row_half_mirror      (i <-> 7-i)
+  if (G >= 16) v += dpp_mov<0x140>(v);         // row_mirror           (i <-> 15-i)
+  if (G >= 32) v += __shfl_xor(v, 16, WAVE);
+  if (G >= 64) v += __shfl_xor(v, 32, WAVE);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Distance kernels on one 16-byte chunk pair.  L2 = sum (x-y)^2, IP = 1 - sum x*y
+// (L2DistanceDispatcher.h:10-17, IPDistanceDispatcher.h:10-16).  Integer element types
+// accumulate exactly in int32 (the reference's float/int32 accumulations agree with that while
+// the sum stays below 2^24).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int METRIC>
+struct Dist;
+
+template <int METRIC>
+struct Dist<float, METRIC> {
+  typedef float acc_t;
+  static __device__ __forceinline__ float chunk(float acc, const uint4& x, const uint4& y) {
+    const float xs[4] = {__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w)};
+    const float ys[4] = {__uint_as_float(y.x), __uint_as_float(y.y), __uint_as_float(y.z), __uint_as_float(y.w)};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (METRIC == FNV_METRIC_L2) {
+        float t = xs[i] - ys[i];
+        acc = fmaf(t, t, acc);
+      } else {
+        acc = fmaf(xs[i], ys[i], acc);
+      }
+    }
+    return acc;
+  }
+  static __device__ __forceinline__ float finish(float s) { return METRIC == FNV_METRIC_L2 ? s : 1.0f - s; }
+};
+
+template <typename T, int METRIC>
+struct DistInt {
+  typedef int acc_t;
+  static __device__ __forceinline__ int elem(uint32_t w, int k) {
+    if (sizeof(T) == 1 && T(-1) < T(0)) return (int)(int8_t)(w >> (8 * k));
+    return (int)((w >> (8 * k)) & 0xffu);
+  }
+  static __device__ __forceinline__ int chunk(int acc, const uint4& x, const uint4& y) {
+    const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+    const uint32_t ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        int a = elem(xs[i], k), b = elem(ys[i], k);
+        if (METRIC == FNV_METRIC_L2) {
+          int t = a - b;
+          acc += t * t;
+        } else {
+          acc += a * b;
+        }
+      }
+    }
+    return acc;
+  }
+  static __device__ __forceinline__ float finish(int s) {
+    return METRIC == FNV_METRIC_L2 ? (float)s : 1.0f - (float)s;
+  }
+};
+template <int METRIC>
+struct Dist<uint8_t, METRIC> : DistInt<uint8_t, METRIC> {};
+template <int METRIC>
+struct Dist<int8_t, METRIC> : DistInt<int8_t, METRIC> {};
+
+// ---------------------------------------------------------------------------------------------
+// Distances from the query (in LDS, zero padded to q_chunks) to `n` nodes whose ids sit in LDS.
+// Lane layout: g = lane % G walks the 16-byte chunks of a row (chunk g, g+G, ...), v = lane / G
+// picks the vector of the pass; a pass covers 64/G vectors; PU passes are fetched together.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int METRIC, int G, int CU>
+__device__ __forceinline__ void compute_dists(const SearchParams& p, const uint4* qlds, const uint32_t* ids, int n,
+                                              float* outd, int lane) {
+  typedef Dist<T, METRIC> D;
+  typedef typename D::acc_t acc_t;
+  constexpr int VPW = WAVE / G;
+  const int g = lane % G;
+  const int v = lane / G;
+  const int nchunks = (int)p.nchunks;
+
+  for (int base = 0; base < n; base += VPW * PU) {
+    acc_t acc[PU];
+    const uint8_t* rowp[PU];
+    bool valid[PU];
+#pragma unroll
+    for (int pu = 0; pu < PU; pu++) {
+      int slot = base + pu * VPW + v;
+      valid[pu] = slot < n;
+      uint32_t id = valid[pu] ? ids[slot] : 0u;
+      rowp[pu] = p.vectors + (uint64_t)id * p.row_bytes;
+      acc[pu] = 0;
+    }
+    for (int c0 = 0; c0 < nchunks; c0 += G * CU) {
+      uint4 y[PU][CU];
+#pragma unroll
+      for (int pu = 0; pu < PU; pu++) {
+        if (base + pu * VPW < n) {  // wave-uniform: skip passes that hold no vector at all
+#pragma unroll
+          for (int cu = 0; cu < CU; cu++) {
+            int c = c0 + cu * G + g;
+            int cc = c < nchunks ? c : nchunks - 1;  // clamp: always a legal address
+            y[pu][cu] = valid[pu] ? *reinterpret_cast<const uint4*>(rowp[pu] + (uint32_t)cc * 16u)
+                                  : make_uint4(0, 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int cu = 0; cu < CU; cu++) {
+        int c = c0 + cu * G + g;
+        uint4 x = qlds[c];  // zero beyond the row (q_chunks covers the last c0 block)
+        bool in_row = c < nchunks;
+#pragma unroll
+        for (int pu = 0; pu < PU; pu++) {
+          if (base + pu * VPW < n) {
+            uint4 yy = y[pu][cu];
+            if (!in_row) yy = x;  // x is zero there: (0-0)^2 = 0 and 0*0 = 0
+            acc[pu] = D::chunk(acc[pu], x, yy);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int pu = 0; pu < PU; pu++) {
+      if (base + pu * VPW < n) {
+        acc_t s = group_sum<G>(acc[pu]);
+        if (g == 0 && valid[pu]) outd[base + pu * VPW + v] = D::finish(s);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact visited set: open addressing (linear probing) over uint32 ids in LDS, filled to at most
+// 3/4; once it would exceed that, the remaining insertions of the query go to a per-slot HBM
+// bitmap (one bit per node) that the slot clears again before its next query.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool visited_insert_lds(uint32_t* tab, uint32_t slots_mask, uint32_t shift, uint32_t id) {
+  uint32_t h = (id * 0x9E3779B1u) >> shift;
+  while (true) {
+    uint32_t cur = tab[h];
+    if (cur == id) return false;
+    if (cur == EMPTY_ID) {
+      uint32_t old = atomicCAS(&tab[h], EMPTY_ID, id);
+      if (old == EMPTY_ID) return true;
+      if (old == id) return false;
+    }
+    h = (h + 1) & slots_mask;
+  }
+}
+__device__ __forceinline__ bool visited_lookup_lds(const uint32_t* tab, uint32_t slots_mask, uint32_t shift,
+                                                   uint32_t id) {
+  uint32_t h = (id * 0x9E3779B1u) >> shift;
+  while (true) {
+    uint32_t cur = tab[h];
+    if (cur == id) return true;
+    if (cur == EMPTY_ID) return false;
+    h = (h + 1) & slots_mask;
+  }
+}
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float rfl(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+// ---------------------------------------------------------------------------------------------
+// The search kernel.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int METRIC, int G, int CU>
+__global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x;
+  uint4* qlds = reinterpret_cast<uint4*>(smem + p.off_q);
+  LdsHeap nbr{reinterpret_cast<unsigned long long*>(smem + p.off_nbr)};
+  CandHeap cand{reinterpret_cast<unsigned long long*>(smem + p.off_cand),
+                p.cand_spill + (uint64_t)blockIdx.x * p.spill_entries, (int)p.cand_slots};
+  uint32_t* vis = reinterpret_cast<uint32_t*>(smem + p.off_vis);
+  uint32_t* stage_ids = reinterpret_cast<uint32_t*>(smem + p.off_stage_ids);
+  float* stage_d = reinterpret_cast<float*>(smem + p.off_stage_d);
+  uint32_t* bitmap = p.ovf_bitmap + (uint64_t)blockIdx.x * p.bitmap_words;
+  const uint32_t vis_mask = p.vis_slots - 1;
+  const int B = p.B;
+  const int K = p.K;
+  const int M = (int)p.M;
+
+  while (true) {
+    int qi = 0;
+    if (lane == 0) qi = (int)atomicAdd(p.dispenser, 1u);
+    qi = rfl(qi);
+    if ((uint32_t)qi >= p.nq) break;
+
+    // ---- stage the query (zero padded) and reset the visited table --------------------------
+    {
+      const T* qsrc = reinterpret_cast<const T*>(p.queries) + (uint64_t)qi * p.dim;
+      T* qdst = reinterpret_cast<T*>(qlds);
+      const int padded = (int)(p.q_chunks * 16u / sizeof(T));
+      for (int i = lane; i < padded; i += WAVE) qdst[i] = i < (int)p.dim ? qsrc[i] : T(0);
+      uint4* v4 = reinterpret_cast<uint4*>(vis);
+      for (uint32_t i = lane; i < p.vis_slots / 4; i += WAVE) v4[i] = make_uint4(EMPTY_ID, EMPTY_ID, EMPTY_ID, EMPTY_ID);
+    }
+    __syncthreads();
+
+    // ---- entry-point selection (Index.h:845-870): argmin over nodes 0, s, 2s, ... -----------
+    float best_d = std::numeric_limits<float>::max();
+    uint32_t best_j = 0;
+    for (uint32_t j0 = 0; j0 < p.n_scan; j0 += WAVE) {
+      int cnt = (int)min((uint32_t)WAVE, p.n_scan - j0);
+      if (lane < cnt) stage_ids[lane] = (j0 + lane) * p.scan_step;
+      __syncthreads();
+      compute_dists<T, METRIC, G, CU>(p, qlds, stage_ids, cnt, stage_d, lane);
+      __syncthreads();
+      if (lane < cnt) {
+        float d = stage_d[lane];
+        if (d < best_d) {  // strict '<': first minimum wins (Index.h:864)
+          best_d = d;
+          best_j = j0 + lane;
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      float od = __shfl_xor(best_d, o, WAVE);
+      uint32_t oj = __shfl_xor(best_j, o, WAVE);
+      if (od < best_d || (od == best_d && oj < best_j)) {
+        best_d = od;
+        best_j = oj;
+      }
+    }
+    const uint32_t entry = best_j * p.scan_step;
+
+    // ---- beam search (Index.h:606-707) -------------------------------------------------------
+    int nbr_n = 1, cand_n = 1;
+    float max_dist = best_d;  // == distance(query, entry): same arithmetic, same bits
+    if (lane == 0) {
+      cand.set(0, fnv_stl::Entry{-best_d, entry});
+      nbr.set(0, fnv_stl::Entry{best_d, entry});
+      visited_insert_lds(vis, vis_mask, p.vis_shift, entry);
+    }
+    uint32_t vis_count = 1;
+    bool ovf = false;
+    int err = ST_OK;
+    uint32_t n_dist = 0, n_hops = 0;
+    __syncthreads();
+
+    while (true) {
+      int node = -1;
+      if (lane == 0 && cand_n > 0) {
+        fnv_stl::Entry top = cand.get(0);
+        if (!(-top.key > max_dist && nbr_n >= B)) {  // Index.h:630
+          fnv_stl::heap_pop(cand, cand_n);
+          node = (int)top.val;
+        }
+      }
+      node = rfl(node);
+      if (node < 0) break;
+      cand_n--;
+      n_hops++;
+
+      for (int m0 = 0; m0 < M; m0 += WAVE) {
+        if (!ovf && vis_count + WAVE > p.vis_limit) ovf = true;
+        const bool act = m0 + lane < M;
+        uint32_t id = EMPTY_ID;
+        if (act) id = p.links[(uint64_t)(uint32_t)node * p.M + m0 + lane];
+        bool isnew = false;
+        if (act) {
+          if (!ovf) {
+            isnew = visited_insert_lds(vis, vis_mask, p.vis_shift, id);
+          } else if (!visited_lookup_lds(vis, vis_mask, p.vis_shift, id)) {
+            uint32_t bit = 1u << (id & 31);
+            uint32_t old = atomicOr(&bitmap[id >> 5], bit);
+            isnew = !(old & bit);
+          }
+        }
+        const unsigned long long newmask = __ballot(isnew);
+        const int n = __popcll(newmask);
+        if (isnew) stage_ids[__popcll(newmask & ((1ull << lane) - 1ull))] = id;  // keeps link order
+        vis_count += n;
+        __syncthreads();
+        if (n == 0) continue;
+        compute_dists<T, METRIC, G, CU>(p, qlds, stage_ids, n, stage_d, lane);
+        __syncthreads();
+        n_dist += n;
+
+        float d = 0.f;
+        uint32_t cid = 0;
+        if (lane < n) {
+          d = stage_d[lane];
+          cid = stage_ids[lane];
+        }
+        // Superset filter: max_dist never grows once the beam is full, so anything that fails
+        // here would also fail the sequential test below.
+        unsigned long long pm = __ballot(lane < n && (nbr_n < B || d < max_dist));
+        while (pm) {
+          const int i = __ffsll((long long)pm) - 1;
+          pm &= pm - 1;
+          const float di = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), i));
+          const uint32_t idi = (uint32_t)__builtin_amdgcn_readlane((int)cid, i);
+          if (nbr_n < B || di < max_dist) {  // Index.h:693
+            if (cand_n >= (int)(p.cand_slots + p.spill_entries)) {
+              err = ST_CAND_OVERFLOW;
+              pm = 0;
+              break;
+            }
+            float md = 0.f;
+            if (lane == 0) {
+              fnv_stl::heap_push(cand, cand_n, fnv_stl::Entry{-di, idi});
+              fnv_stl::heap_push(nbr, nbr_n, fnv_stl::Entry{di, idi});
+              if (nbr_n + 1 > B) fnv_stl::heap_pop(nbr, nbr_n + 1);
+              md = nbr.get(0).key;
+            }
+            cand_n++;
+            if (nbr_n < B) nbr_n++;
+            max_dist = rfl(md);
+          }
+        }
+        __syncthreads();
+        if (err) break;
+      }
+      if (err) break;
+    }
+
+    // ---- results (Index.h:393-408): drain, std::sort by distance, truncate to K --------------
+    __syncthreads();
+    const int n = nbr_n;
+    const int cnt = n < K ? n : K;
+    unsigned long long* res = reinterpret_cast<unsigned long long*>(smem + p.off_cand);  // candidates are dead now
+    bool tie = false;
+    for (int e = lane; e < n; e += WAVE) {
+      const fnv_stl::Entry me = nbr.get(e);
+      int rank = 0;
+      bool eq = false;
+      for (int j = 0; j < n; j++) {
+        const float dj = nbr.get(j).key;
+        rank += (dj < me.key || (dj == me.key && j < e)) ? 1 : 0;
+        eq |= (dj == me.key && j != e);
+      }
+      if (rank < K) {
+        res[rank] = pack(me);
+        tie |= eq;  // a tie that reaches into the first K positions: order is the library's
+      }
+    }
+    const bool any_tie = __ballot(tie) != 0ull;
+    __syncthreads();
+    if (any_tie) {
+      // Exact replay of the reference's tail: pop everything (descending), std::sort ascending.
+      if (lane == 0) {
+        for (int m = n; m > 1; m--) fnv_stl::heap_pop(nbr, m);  // leaves nbr[] ascending
+        for (int i = 0; i < n; i++) res[i] = nbr.p[n - 1 - i];  // pop order = descending
+        LdsHeap r{res};
+        fnv_stl::sort_by_key(r, n);
+      }
+      __syncthreads();
+    }
+    for (int k = lane; k < K; k += WAVE) {
+      float od = std::numeric_limits<float>::infinity();
+      int32_t ol = -1;
+      if (k < cnt && !err) {
+        fnv_stl::Entry e = unpack(res[k]);
+        od = e.key;
+        ol = p.labels[e.val];
+      }
+      p.out_dist[(uint64_t)qi * K + k] = od;
+      p.out_labels[(uint64_t)qi * K + k] = ol;
+    }
+    if (lane == 0) {
+      if (p.out_count) p.out_count[qi] = err ? 0 : cnt;
+      if (p.out_ndist) p.out_ndist[qi] = n_dist;
+      if (p.out_nhops) p.out_nhops[qi] = n_hops;
+      if (err) atomicMax(p.status, err);
+    }
+    if (ovf) {  // give the spill bitmap back zeroed
+      __threadfence();
+      for (uint32_t i = lane; i < p.bitmap_words; i += WAVE) bitmap[i] = 0u;
+      __threadfence();
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// U1: AoS -> SoA re-layout of a staged block of nodes.  One thread per (node, 4-byte word) when
+// everything is word aligned, else per byte.  Links: ids >= n_nodes are flagged; duplicates inside
+// a row are replaced by the node's own id (== already visited, see header comment).
+// ---------------------------------------------------------------------------------------------
+__global__ void relayout_vectors_kernel(const uint8_t* __restrict__ aos, uint64_t node_size, uint64_t data_size,
+                                        uint32_t row_bytes, uint64_t first_node, uint64_t count,
+                                        uint8_t* __restrict__ vectors, int word_ok) {
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (word_ok) {
+    const uint32_t wpr = row_bytes / 4;
+    const uint64_t node = tid / wpr;
+    const uint32_t w = (uint32_t)(tid % wpr);
+    if (node >= count) return;
+    uint32_t val = 0;
+    if ((uint64_t)w * 4 < data_size) val = *reinterpret_cast<const uint32_t*>(aos + node * node_size + (uint64_t)w * 4);
+    *reinterpret_cast<uint32_t*>(vectors + (first_node + node) * row_bytes + (uint64_t)w * 4) = val;
+  } else {
+    const uint64_t node = tid / row_bytes;
+    const uint32_t b = (uint32_t)(tid % row_bytes);
+    if (node >= count) return;
+    vectors[(first_node + node) * row_bytes + b] = b < data_size ? aos[node * node_size + b] : (uint8_t)0;
+  }
+}
+
+__global__ void relayout_links_kernel(const uint8_t* __restrict__ aos, uint64_t node_size, uint64_t data_size,
+                                      uint32_t M, uint64_t first_node, uint64_t count, uint64_t n_nodes,
+                                      uint32_t* __restrict__ links, int32_t* __restrict__ labels, int* bad_flag) {
+  const uint64_t node = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= count) return;
+  const uint8_t* base = aos + node * node_size + data_size;
+  const uint32_t self = (uint32_t)(first_node + node);
+  uint32_t* out = links + (first_node + node) * M;
+  for (uint32_t i = 0; i < M; i++) {
+    uint32_t id;
+    memcpy(&id, base + (uint64_t)i * 4, 4);
+    if ((uint64_t)id >= n_nodes) {
+      atomicExch(bad_flag, 1);
+      id = self;
+    }
+    for (uint32_t j = 0; j < i; j++) {
+      uint32_t prev;
+      memcpy(&prev, base + (uint64_t)j * 4, 4);
+      if (prev == id) {
+        id = self;
+        break;
+      }
+    }
+    out[i] = id;
+  }
+  int32_t lab;
+  memcpy(&lab, base + (uint64_t)M * 4, 4);
+  labels[first_node + node] = lab;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t _e = (expr);                                                                             \
+    if (_e != hipSuccess)                                                                               \
+      return fail(FNV_ERR_NO_DEVICE, std::string(#expr) + " failed: " + hipGetErrorString(_e));        \
+  } while (0)
+
+size_t dtype_size(int dt) { return dt == FNV_DTYPE_FLOAT32 ? 4 : (dt == FNV_DTYPE_UINT8 || dt == FNV_DTYPE_INT8) ? 1 : 0; }
+
+typedef void (*kernel_fn)(const SearchParams);
+
+struct KernelCfg {
+  int G, CU;
+};
+// chunks covered per inner iteration = G*CU: 8,16,32,64,128,256 (128 B ... 4 KiB of a row)
+const KernelCfg kCfgs[] = {{8, 1}, {8, 2}, {8, 4}, {16, 4}, {32, 4}, {64, 4}};
+constexpr int kNumCfgs = 6;
+
+template <typename T, int METRIC>
+kernel_fn pick_cfg(int c) {
+  switch (c) {
+    case 0: return beam_search_kernel<T, METRIC, 8, 1>;
+    case 1: return beam_search_kernel<T, METRIC, 8, 2>;
+    case 2: return beam_search_kernel<T, METRIC, 8, 4>;
+    case 3: return beam_search_kernel<T, METRIC, 16, 4>;
+    case 4: return beam_search_kernel<T, METRIC, 32, 4>;
+    default: return beam_search_kernel<T, METRIC, 64, 4>;
+  }
+}
+
+kernel_fn pick_kernel(int dtype, int metric, int cfg) {
+  if (dtype == FNV_DTYPE_FLOAT32) return metric == FNV_METRIC_L2 ? pick_cfg<float, FNV_METRIC_L2>(cfg) : pick_cfg<float, FNV_METRIC_IP>(cfg);
+  if (dtype == FNV_DTYPE_UINT8) return metric == FNV_METRIC_L2 ? pick_cfg<uint8_t, FNV_METRIC_L2>(cfg) : pick_cfg<uint8_t, FNV_METRIC_IP>(cfg);
+  return metric == FNV_METRIC_L2 ? pick_cfg<int8_t, FNV_METRIC_L2>(cfg) : pick_cfg<int8_t, FNV_METRIC_IP>(cfg);
+}
+
+}  // namespace
+
+struct fnv_index_s {
+  int device = 0;
+  int dtype = FNV_DTYPE_FLOAT32, metric = FNV_METRIC_L2;
+  uint32_t M = 0, dim = 0, row_bytes = 0;
+  uint64_t n_nodes = 0;
+  uint8_t* d_vectors = nullptr;
+  uint32_t* d_links = nullptr;
+  int32_t* d_labels = nullptr;
+  int num_cus = 0;
+  // options
+  int64_t visited_factor = 32, visited_slots = 0, cand_factor = 3, cand_slots = 0, spill_entries = 16384,
+          blocks_per_cu = 0;
+  // workspace (grown on demand)
+  uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status
+  uint32_t* d_bitmap = nullptr;
+  size_t bitmap_bytes = 0;
+  unsigned long long* d_spill = nullptr;
+  size_t spill_bytes = 0;
+  // staging for the host-buffer entry point
+  void* d_q = nullptr;
+  size_t d_q_bytes = 0;
+  void* d_out = nullptr;
+  size_t d_out_bytes = 0;
+  hipStream_t stream = nullptr;  // owned, used by fnv_search_batch
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool launched = false;
+  uint64_t geom[6] = {0, 0, 0, 0, 0, 0};
+  std::mutex mu;
+};
+
+namespace {
+
+int index_common_init(fnv_index_s* ix) {
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, ix->device));
+  ix->num_cus = prop.multiProcessorCount;
+  HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&ix->ev0));
+  HIP_TRY(hipEventCreate(&ix->ev1));
+  HIP_TRY(hipMalloc(&ix->d_dispenser, 2 * sizeof(uint32_t)));
+  HIP_TRY(hipMemset(ix->d_dispenser, 0, 2 * sizeof(uint32_t)));
+  return FNV_OK;
+}
+
+int validate_geometry(uint32_t M, uint64_t n_nodes, int data_type, int metric, uint32_t dim) {
+  if (dtype_size(data_type) == 0) return fail(FNV_ERR_RUNTIME, "Unsupported data type");
+  if (metric != FNV_METRIC_L2 && metric != FNV_METRIC_IP) return fail(FNV_ERR_INVALID, "Invalid metric");
+  if (M == 0 || dim == 0) return fail(FNV_ERR_INVALID, "M and dim must be positive");
+  if (n_nodes == 0) return fail(FNV_ERR_INVALID, "cannot upload an empty index");
+  if (n_nodes >= 0xFFFFFFFFull) return fail(FNV_ERR_INVALID, "too many nodes for 32-bit node ids");
+  return FNV_OK;
+}
+
+int alloc_buffers(fnv_index_s* ix) {
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(hipMalloc(&ix->d_vectors, ix->n_nodes * (uint64_t)ix->row_bytes));
+  HIP_TRY(hipMalloc(&ix->d_links, ix->n_nodes * (uint64_t)ix->M * 4));
+  HIP_TRY(hipMalloc(&ix->d_labels, ix->n_nodes * 4));
+  return index_common_init(ix);
+}
+
+uint32_t pow2_ceil(uint64_t v) {
+  uint32_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fnv_last_error(void) { return g_err.c_str(); }
+const char* fnv_version(void) { return "flatnav_hip gfx950 r1"; }
+
+int fnv_device_count(int* count) {
+  if (!count) return fail(FNV_ERR_INVALID, "count is null");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(FNV_ERR_NO_DEVICE, std::string("hipGetDeviceCount failed: ") + hipGetErrorString(e));
+  }
+  *count = n;
+  return FNV_OK;
+}
+
+int fnv_index_alloc(uint32_t M, uint64_t n_nodes, int data_type, int metric, uint32_t dim, int device,
+                    fnv_index_t* out) {
+  if (!out) return fail(FNV_ERR_INVALID, "out is null");
+  int rc = validate_geometry(M, n_nodes, data_type, metric, dim);
+  if (rc) return rc;
+  fnv_index_s* ix = new fnv_index_s();
+  ix->device = device;
+  ix->dtype = data_type;
+  ix->metric = metric;
+  ix->M = M;
+  ix->dim = dim;
+  ix->n_nodes = n_nodes;
+  ix->row_bytes = (uint32_t)((dim * dtype_size(data_type) + 15) / 16 * 16);
+  rc = alloc_buffers(ix);
+  if (rc) {
+    fnv_index_free(ix);
+    return rc;
+  }
+  *out = ix;
+  return FNV_OK;
+}
+
+int fnv_index_upload(const void* aos_blob, uint64_t node_size, uint64_t data_size, uint32_t M, uint64_t n_nodes,
+                     int data_type, int metric, uint32_t dim, int device, fnv_index_t* out) {
+  if (!aos_blob || !out) return fail(FNV_ERR_INVALID, "null argument");
+  int rc = validate_geometry(M, n_nodes, data_type, metric, dim);
+  if (rc) return rc;
+  if (data_size != (uint64_t)dim * dtype_size(data_type) || node_size != data_size + 4ull * M + 4)
+    return fail(FNV_ERR_INVALID, "node geometry does not match [data][M links][label] (Index.h:176)");
+  fnv_index_t ix = nullptr;
+  rc = fnv_index_alloc(M, n_nodes, data_type, metric, dim, device, &ix);
+  if (rc) return rc;
+
+  const uint64_t chunk_nodes = std::max<uint64_t>(1, (256ull << 20) / node_size);
+  uint8_t* d_stage = nullptr;
+  int* d_bad = nullptr;
+  auto cleanup = [&]() {
+    if (d_stage) (void)hipFree(d_stage);
+    if (d_bad) (void)hipFree(d_bad);
+  };
+#define UP_TRY(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess) {                                                                            \
+      cleanup();                                                                                       \
+      fnv_index_free(ix);                                                                              \
+      return fail(FNV_ERR_NO_DEVICE, std::string(#expr) + " failed: " + hipGetErrorString(_e));       \
+    }                                                                                                  \
+  } while (0)
+  UP_TRY(hipMalloc(&d_stage, std::min(chunk_nodes, n_nodes) * node_size));
+  UP_TRY(hipMalloc(&d_bad, sizeof(int)));
+  UP_TRY(hipMemset(d_bad, 0, sizeof(int)));
+  const int word_ok = (node_size % 4 == 0 && data_size % 4 == 0) ? 1 : 0;
+  for (uint64_t first = 0; first < n_nodes; first += chunk_nodes) {
+    const uint64_t count = std::min(chunk_nodes, n_nodes - first);
+    UP_TRY(hipMemcpy(d_stage, (const uint8_t*)aos_blob + first * node_size, count * node_size, hipMemcpyHostToDevice));
+    const uint64_t units = count * (word_ok ? ix->row_bytes / 4 : ix->row_bytes);
+    hipLaunchKernelGGL(relayout_vectors_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, 0, d_stage,
+                       node_size, data_size, ix->row_bytes, first, count, ix->d_vectors, word_ok);
+    hipLaunchKernelGGL(relayout_links_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, d_stage,
+                       node_size, data_size, M, first, count, n_nodes, ix->d_links, ix->d_labels, d_bad);
+    UP_TRY(hipGetLastError());
+    UP_TRY(hipDeviceSynchronize());
+  }
+  int bad = 0;
+  UP_TRY(hipMemcpy(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost));
+  cleanup();
+#undef UP_TRY
+  if (bad) {
+    fnv_index_free(ix);
+    return fail(FNV_ERR_RUNTIME, "index blob holds link ids outside [0, n_nodes)");
+  }
+  *out = ix;
+  return FNV_OK;
+}
+
+int fnv_index_device_buffers(fnv_index_t ix, void* ptrs[3], uint64_t sizes[3]) {
+  if (!ix || !ptrs || !sizes) return fail(FNV_ERR_INVALID, "null argument");
+  ptrs[0] = ix->d_vectors;
+  ptrs[1] = ix->d_links;
+  ptrs[2] = ix->d_labels;
+  sizes[0] = ix->n_nodes * (uint64_t)ix->row_bytes;
+  sizes[1] = ix->n_nodes * (uint64_t)ix->M * 4;
+  sizes[2] = ix->n_nodes * 4;
+  return FNV_OK;
+}
+
+int fnv_index_info(fnv_index_t ix, uint64_t info[8]) {
+  if (!ix || !info) return fail(FNV_ERR_INVALID, "null argument");
+  info[0] = (uint64_t)ix->dtype;
+  info[1] = ix->M;
+  info[2] = ix->row_bytes;
+  info[3] = ix->n_nodes;
+  info[4] = ix->dim;
+  info[5] = (uint64_t)ix->metric;
+  info[6] = (uint64_t)ix->device;
+  info[7] = ix->n_nodes * ((uint64_t)ix->row_bytes + 4ull * ix->M + 4) + ix->bitmap_bytes + ix->spill_bytes;
+  return FNV_OK;
+}
+
+int fnv_index_free(fnv_index_t ix) {
+  if (!ix) return FNV_OK;
+  (void)hipSetDevice(ix->device);
+  if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_bitmap, ix->d_spill, ix->d_q, ix->d_out};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  if (ix->ev0) (void)hipEventDestroy(ix->ev0);
+  if (ix->ev1) (void)hipEventDestroy(ix->ev1);
+  if (ix->stream) (void)hipStreamDestroy(ix->stream);
+  delete ix;
+  return FNV_OK;
+}
+
+int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
+  if (!ix || !name) return fail(FNV_ERR_INVALID, "null argument");
+  std::string n(name);
+  if (value < 0) return fail(FNV_ERR_INVALID, "option values must be non-negative");
+  if (n == "visited_factor") ix->visited_factor = std::max<int64_t>(1, value);
+  else if (n == "visited_slots") {
+    if (value && (value & (value - 1))) return fail(FNV_ERR_INVALID, "visited_slots must be a power of two");
+    if (value && value < 256) return fail(FNV_ERR_INVALID, "visited_slots must be at least 256");
+    ix->visited_slots = value;
+  } else if (n == "cand_factor") ix->cand_factor = std::max<int64_t>(1, value);
+  else if (n == "cand_slots") ix->cand_slots = value;
+  else if (n == "spill_entries") ix->spill_entries = std::max<int64_t>(1, value);
+  else if (n == "blocks_per_cu") ix->blocks_per_cu = value;
+  else return fail(FNV_ERR_INVALID, "unknown option: " + n);
+  return FNV_OK;
+}
+
+int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, int K, int ef_search,
+                            int num_initializations, float* d_out_dist, int32_t* d_out_labels,
+                            int32_t* d_out_count, uint64_t* d_out_ndist, uint64_t* d_out_nhops, void* hip_stream) {
+  if (!ix) return fail(FNV_ERR_INVALID, "index is null");
+  // Index.h:847-849
+  if (num_initializations <= 0) return fail(FNV_ERR_INVALID, "num_initializations must be greater than 0.");
+  if (K <= 0 || ef_search <= 0) return fail(FNV_ERR_INVALID, "K and ef_search must be positive");
+  if (nq == 0) return FNV_OK;
+  if (!d_queries || !d_out_dist || !d_out_labels) return fail(FNV_ERR_INVALID, "null buffer");
+  if (nq > 0x7FFFFFFFull) return fail(FNV_ERR_INVALID, "too many queries in one batch");
+  std::lock_guard<std::mutex> lock(ix->mu);
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t stream = (hipStream_t)hip_stream;
+
+  SearchParams p;
+  memset(&p, 0, sizeof(p));
+  p.vectors = ix->d_vectors;
+  p.links = ix->d_links;
+  p.labels = ix->d_labels;
+  p.queries = (const uint8_t*)d_queries;
+  p.out_dist = d_out_dist;
+  p.out_labels = d_out_labels;
+  p.out_count = d_out_count;
+  p.out_ndist = d_out_ndist;
+  p.out_nhops = d_out_nhops;
+  p.n_nodes = ix->n_nodes;
+  p.nq = (uint32_t)nq;
+  p.M = ix->M;
+  p.dim = ix->dim;
+  p.row_bytes = ix->row_bytes;
+  p.nchunks = ix->row_bytes / 16;
+  p.K = K;
+  p.B = std::max(ef_search, K);  // Index.h:392
+  // Index.h:851-861: step = max(1, N / n_init); nodes 0, step, 2*step, ... < N
+  uint64_t step = ix->n_nodes / (uint64_t)num_initializations;
+  if (step == 0) step = 1;
+  p.scan_step = (uint32_t)step;
+  p.n_scan = (uint32_t)((ix->n_nodes + step - 1) / step);
+
+  int cfg = kNumCfgs - 1;
+  for (int c = 0; c < kNumCfgs; c++)
+    if ((uint32_t)(kCfgs[c].G * kCfgs[c].CU) >= p.nchunks) {
+      cfg = c;
+      break;
+    }
+  const uint32_t per_iter = (uint32_t)(kCfgs[cfg].G * kCfgs[cfg].CU);
+  p.q_chunks = (p.nchunks + per_iter - 1) / per_iter * per_iter;
+
+  p.vis_slots = ix->visited_slots ? (uint32_t)ix->visited_slots
+                                  : std::max<uint32_t>(256, pow2_ceil((uint64_t)ix->visited_factor * (uint64_t)p.B));
+  p.vis_slots = std::min<uint32_t>(p.vis_slots, 1u << 15);  // 128 KiB of LDS at most
+  p.vis_shift = 32;
+  for (uint32_t s = p.vis_slots; s > 1; s >>= 1) p.vis_shift--;
+  p.vis_limit = p.vis_slots / 4 * 3;
+  p.cand_slots = ix->cand_slots ? (uint32_t)ix->cand_slots : (uint32_t)(ix->cand_factor * p.B);
+  p.cand_slots = std::max<uint32_t>(p.cand_slots, (uint32_t)p.B + 1);  // also hosts the final result list
+  p.spill_entries = (uint32_t)ix->spill_entries;
+  p.bitmap_words = (uint32_t)((ix->n_nodes + 31) / 32);
+
+  auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+  uint32_t off = 0;
+  p.off_q = off;
+  off = align16(off + p.q_chunks * 16);
+  p.off_nbr = off;
+  off = align16(off + ((uint32_t)p.B + 2) * 8);
+  p.off_cand = off;
+  off = align16(off + p.cand_slots * 8);
+  p.off_vis = off;
+  off = align16(off + p.vis_slots * 4);
+  p.off_stage_ids = off;
+  off = align16(off + WAVE * 4);
+  p.off_stage_d = off;
+  off = align16(off + WAVE * 4);
+  const uint32_t lds_bytes = off;
+  if (lds_bytes > 160u * 1024u)
+    return fail(FNV_ERR_INVALID, "ef_search too large for the on-chip beam state (needs " + std::to_string(lds_bytes) +
+                                     " bytes of LDS, 163840 available); lower ef_search or the *_slots options");
+
+  kernel_fn kern = pick_kernel(ix->dtype, ix->metric, cfg);
+  HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  int bpc = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, WAVE, lds_bytes));
+  if (bpc < 1) bpc = 1;
+  if (ix->blocks_per_cu > 0) bpc = std::min<int>(bpc, (int)ix->blocks_per_cu);
+  const uint32_t nslots = (uint32_t)std::min<uint64_t>(nq, (uint64_t)bpc * (uint64_t)ix->num_cus);
+
+  // workspace
+  const size_t need_bitmap = (size_t)nslots * p.bitmap_words * 4;
+  if (need_bitmap > ix->bitmap_bytes) {
+    if (ix->d_bitmap) HIP_TRY(hipFree(ix->d_bitmap));
+    ix->d_bitmap = nullptr;
+    ix->bitmap_bytes = 0;
+    HIP_TRY(hipMalloc(&ix->d_bitmap, need_bitmap));
+    HIP_TRY(hipMemset(ix->d_bitmap, 0, need_bitmap));
+    ix->bitmap_bytes = need_bitmap;
+  }
+  const size_t need_spill = (size_t)nslots * p.spill_entries * 8;
+  if (need_spill > ix->spill_bytes) {
+    if (ix->d_spill) HIP_TRY(hipFree(ix->d_spill));
+    ix->d_spill = nullptr;
+    ix->spill_bytes = 0;
+    HIP_TRY(hipMalloc(&ix->d_spill, need_spill));
+    ix->spill_bytes = need_spill;
+  }
+  p.ovf_bitmap = ix->d_bitmap;
+  p.cand_spill = ix->d_spill;
+  p.dispenser = ix->d_dispenser;
+  p.status = (int32_t*)(ix->d_dispenser + 1);
+
+  HIP_TRY(hipMemsetAsync(ix->d_dispenser, 0, 2 * sizeof(uint32_t), stream));
+  HIP_TRY(hipEventRecord(ix->ev0, stream));
+  hipLaunchKernelGGL(kern, dim3(nslots), dim3(WAVE), lds_bytes, stream, p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ix->ev1, stream));
+  ix->last_stream = stream;
+  ix->launched = true;
+  ix->geom[0] = nslots;
+  ix->geom[1] = WAVE;
+  ix->geom[2] = lds_bytes;
+  ix->geom[3] = (uint64_t)bpc;
+  ix->geom[4] = p.vis_slots;
+  ix->geom[5] = p.cand_slots;
+  return FNV_OK;
+}
+
+int fnv_search_status(fnv_index_t ix) {
+  if (!ix) return fail(FNV_ERR_INVALID, "index is null");
+  if (!ix->launched) return FNV_OK;
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(hipStreamSynchronize(ix->last_stream));
+  int32_t st = 0;
+  HIP_TRY(hipMemcpy(&st, ix->d_dispenser + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (st == ST_CAND_OVERFLOW)
+    return fail(FNV_ERR_CAPACITY, "candidate heap overflowed its HBM spill area; raise the spill_entries option");
+  return FNV_OK;
+}
+
+int fnv_search_batch(fnv_index_t ix, const void* queries, uint64_t nq, int K, int ef_search, int num_initializations,
+                     float* out_dist, int32_t* out_labels, int32_t* out_count, uint64_t* out_ndist,
+                     uint64_t* out_nhops) {
+  if (!ix) return fail(FNV_ERR_INVALID, "index is null");
+  if (num_initializations <= 0) return fail(FNV_ERR_INVALID, "num_initializations must be greater than 0.");
+  if (K <= 0 || ef_search <= 0) return fail(FNV_ERR_INVALID, "K and ef_search must be positive");
+  if (nq == 0) return FNV_OK;
+  if (!queries || !out_dist || !out_labels) return fail(FNV_ERR_INVALID, "null buffer");
+  HIP_TRY(hipSetDevice(ix->device));
+  const size_t qbytes = (size_t)nq * ix->dim * dtype_size(ix->dtype);
+  // one output slab: dist | labels | count | ndist | nhops
+  const size_t o_dist = 0;
+  const size_t o_lab = o_dist + (size_t)nq * K * 4;
+  const size_t o_cnt = o_lab + (size_t)nq * K * 4;
+  const size_t o_nd = (o_cnt + (size_t)nq * 4 + 7) & ~(size_t)7;
+  const size_t o_nh = o_nd + (size_t)nq * 8;
+  const size_t obytes = o_nh + (size_t)nq * 8;
+  {
+    std::lock_guard<std::mutex> lock(ix->mu);
+    if (qbytes > ix->d_q_bytes) {
+      if (ix->d_q) HIP_TRY(hipFree(ix->d_q));
+      ix->d_q = nullptr;
+      ix->d_q_bytes = 0;
+      HIP_TRY(hipMalloc(&ix->d_q, qbytes));
+      ix->d_q_bytes = qbytes;
+    }
+    if (obytes > ix->d_out_bytes) {
+      if (ix->d_out) HIP_TRY(hipFree(ix->d_out));
+      ix->d_out = nullptr;
+      ix->d_out_bytes = 0;
+      HIP_TRY(hipMalloc(&ix->d_out, obytes));
+      ix->d_out_bytes = obytes;
+    }
+  }
+  uint8_t* o = (uint8_t*)ix->d_out;
+  HIP_TRY(hipMemcpyAsync(ix->d_q, queries, qbytes, hipMemcpyHostToDevice, ix->stream));
+  int rc = fnv_search_batch_device(ix, ix->d_q, nq, K, ef_search, num_initializations, (float*)(o + o_dist),
+                                   (int32_t*)(o + o_lab), (int32_t*)(o + o_cnt), (uint64_t*)(o + o_nd),
+                                   (uint64_t*)(o + o_nh), ix->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out_dist, o + o_dist, (size_t)nq * K * 4, hipMemcpyDeviceToHost, ix->stream));
+  HIP_TRY(hipMemcpyAsync(out_labels, o + o_lab, (size_t)nq * K * 4, hipMemcpyDeviceToHost, ix->stream));
+  if (out_count) HIP_TRY(hipMemcpyAsync(out_count, o + o_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, ix->stream));
+  if (out_ndist) HIP_TRY(hipMemcpyAsync(out_ndist, o + o_nd, (size_t)nq * 8, hipMemcpyDeviceToHost, ix->stream));
+  if (out_nhops) HIP_TRY(hipMemcpyAsync(out_nhops, o + o_nh, (size_t)nq * 8, hipMemcpyDeviceToHost, ix->stream));
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  return fnv_search_status(ix);
+}
+
+int fnv_last_kernel_ms(fnv_index_t ix, float* ms) {
+  if (!ix || !ms) return fail(FNV_ERR_INVALID, "null argument");
+  if (!ix->launched) return fail(FNV_ERR_RUNTIME, "no search has been launched on this index");
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(hipEventSynchronize(ix->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, ix->ev0, ix->ev1));
+  return FNV_OK;
+}
+
+int fnv_last_launch_geometry(fnv_index_t ix, uint64_t geom[6]) {
+  if (!ix || !geom) return fail(FNV_ERR_INVALID, "null argument");
+  for (int i = 0; i < 6; i++) geom[i] = ix->geom[i];
+  return FNV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,180 @@
+"""ctypes binding of the C ABI in include/flatnav_hip.h (libflatnav_hip.so, gfx950).
+
+This is the only way Python code reaches the device search path.  There is NO CPU fallback: if the
+shared library is missing or no MI355X is visible, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libflatnav_hip.so")
+
+FNV_OK, FNV_ERR_INVALID, FNV_ERR_RUNTIME, FNV_ERR_NO_DEVICE, FNV_ERR_CAPACITY = 0, 1, 2, 3, 4
+DTYPE_ORD = {"float32": 9, "uint8": 0, "int8": 4}
+ORD_DTYPE = {v: k for k, v in DTYPE_ORD.items()}
+METRIC_ORD = {"l2": 0, "angular": 1, "ip": 1}
+
+# every symbol include/flatnav_hip.h declares (tests check the library exports exactly these)
+C_ABI_SYMBOLS = [
+    "fnv_last_error", "fnv_version", "fnv_device_count", "fnv_index_upload", "fnv_index_alloc",
+    "fnv_index_device_buffers", "fnv_index_info", "fnv_index_free", "fnv_set_option", "fnv_search_batch",
+    "fnv_search_batch_device", "fnv_search_status", "fnv_last_kernel_ms", "fnv_last_launch_geometry",
+]
+
+_lib = None
+
+
+class DeviceUnavailable(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load libflatnav_hip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DeviceUnavailable(
+            "flatnav_amd: %s is missing -- build it with `python -m flatnav_amd.build` "
+            "(there is no CPU fallback for the search path)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.fnv_last_error.restype = C.c_char_p
+    L.fnv_version.restype = C.c_char_p
+    L.fnv_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.fnv_index_upload.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.c_int,
+                                   C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
+    L.fnv_index_alloc.argtypes = [C.c_uint32, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.c_int,
+                                  C.POINTER(C.c_void_p)]
+    L.fnv_index_device_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.fnv_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.fnv_index_free.argtypes = [C.c_void_p]
+    L.fnv_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.fnv_search_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
+    L.fnv_search_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int] + [
+        C.c_void_p] * 6
+    L.fnv_search_status.argtypes = [C.c_void_p]
+    L.fnv_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.fnv_last_launch_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    """Map C-ABI status codes onto the exceptions the reference raises at the same points."""
+    if rc == FNV_OK:
+        return
+    msg = lib().fnv_last_error().decode()
+    if rc == FNV_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == FNV_ERR_NO_DEVICE:
+        raise DeviceUnavailable(msg)
+    raise RuntimeError(msg)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(lib().fnv_device_count(C.byref(n)))
+    return n.value
+
+
+def _np_dtype(name: str):
+    return {"float32": np.float32, "uint8": np.uint8, "int8": np.int8}[name]
+
+
+class DeviceIndex:
+    """An index resident in one GPU's HBM (vectors / links / labels in SoA form)."""
+
+    def __init__(self, handle: C.c_void_p):
+        self._h = handle
+        info = (C.c_uint64 * 8)()
+        check(lib().fnv_index_info(self._h, info))
+        self.dtype = ORD_DTYPE[int(info[0])]
+        self.M = int(info[1])
+        self.row_bytes = int(info[2])
+        self.n_nodes = int(info[3])
+        self.dim = int(info[4])
+        self.metric = "l2" if int(info[5]) == 0 else "angular"
+        self.device = int(info[6])
+
+    @classmethod
+    def upload(cls, blob: np.ndarray, node_size: int, data_size: int, M: int, n_nodes: int, dtype: str,
+               metric: str, dim: int, device: int = 0) -> "DeviceIndex":
+        blob = np.ascontiguousarray(blob).view(np.uint8).reshape(-1)
+        if blob.size < node_size * n_nodes:
+            raise ValueError("blob smaller than n_nodes * node_size")
+        h = C.c_void_p()
+        check(lib().fnv_index_upload(blob.ctypes.data, node_size, data_size, M, n_nodes, DTYPE_ORD[dtype],
+                                     METRIC_ORD[metric], dim, device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def alloc(cls, M: int, n_nodes: int, dtype: str, metric: str, dim: int, device: int = 0) -> "DeviceIndex":
+        h = C.c_void_p()
+        check(lib().fnv_index_alloc(M, n_nodes, DTYPE_ORD[dtype], METRIC_ORD[metric], dim, device, C.byref(h)))
+        return cls(h)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().fnv_index_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_buffers(self):
+        """[(ptr, nbytes)] * 3 for vectors, links, labels (for RCCL broadcast / peer copies)."""
+        ptrs = (C.c_void_p * 3)()
+        sizes = (C.c_uint64 * 3)()
+        check(lib().fnv_index_device_buffers(self._h, ptrs, sizes))
+        return [(int(ptrs[i] or 0), int(sizes[i])) for i in range(3)]
+
+    def set_option(self, name: str, value: int) -> None:
+        check(lib().fnv_set_option(self._h, name.encode(), int(value)))
+
+    def search(self, queries, K: int, ef_search: int, num_initializations: int = 100, stats: bool = False):
+        """Host-buffer batched search -> (dist float32[Q,K], labels int32[Q,K][, stats])."""
+        q = np.ascontiguousarray(queries, dtype=_np_dtype(self.dtype))
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError("Queries have incorrect dimensions.")
+        nq = q.shape[0]
+        if K <= 0:
+            raise ValueError("K must be positive")
+        d = np.empty((nq, K), dtype=np.float32)
+        l = np.empty((nq, K), dtype=np.int32)
+        cnt = np.empty(nq, dtype=np.int32)
+        nd = np.zeros(nq, dtype=np.uint64)
+        nh = np.zeros(nq, dtype=np.uint64)
+        check(lib().fnv_search_batch(self._h, q.ctypes.data, nq, K, ef_search, num_initializations, d.ctypes.data,
+                                     l.ctypes.data, cnt.ctypes.data, nd.ctypes.data, nh.ctypes.data))
+        if stats:
+            return d, l, {"count": cnt, "n_dist": nd, "n_hops": nh}
+        return d, l
+
+    def search_device(self, q_ptr: int, nq: int, K: int, ef_search: int, num_initializations: int, dist_ptr: int,
+                      label_ptr: int, count_ptr: int = 0, ndist_ptr: int = 0, nhops_ptr: int = 0,
+                      stream: int = 0) -> None:
+        """Device-buffer batched search, enqueued on `stream` (raw hipStream_t handle, 0 = null stream)."""
+        check(lib().fnv_search_batch_device(self._h, q_ptr, nq, K, ef_search, num_initializations, dist_ptr,
+                                            label_ptr, count_ptr or None, ndist_ptr or None, nhops_ptr or None,
+                                            stream or None))
+
+    def status(self) -> None:
+        check(lib().fnv_search_status(self._h))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float(0)
+        check(lib().fnv_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def launch_geometry(self) -> dict:
+        g = (C.c_uint64 * 6)()
+        check(lib().fnv_last_launch_geometry(self._h, g))
+        keys = ["grid_blocks", "block_threads", "lds_bytes", "blocks_per_cu", "visited_slots", "cand_slots"]
+        return {k: int(g[i]) for i, k in enumerate(keys)}

@@ -1,0 +1,136 @@
+/* flatnav_hip.h -- C ABI of the MI355X (gfx950) flat-NSW search engine.
+ *
+ * This is the drop-in boundary for ONE path of BlaiseMuhirwa/flatnav: batched
+ * k-NN search (greedy beam traversal over the flat navigable-small-world graph).
+ * Everything here is plain C: opaque handle, pointers, sizes, int status codes.
+ * No torch / pybind / C++ types cross this line.
+ *
+ * Reference interfaces each entry point stands in for (paths relative to the
+ * reference repository root):
+ *
+ *   fnv_index_upload        the host index memory that search reads:
+ *                           include/flatnav/index/Index.h:56 (_index_memory),
+ *                           :61-63 and :555-573 (AoS node = [data][M links][label]),
+ *                           as produced by Index::add / Index::loadIndex (:353, :442).
+ *   fnv_search_batch        the batched search loop of the Python binding,
+ *                           python-bindings/src/flatnav/bindings.cpp:161-228
+ *                           (searchImpl: for each query Index::search + copy K results),
+ *                           i.e. Index::search, include/flatnav/index/Index.h:387-409 with
+ *                           initializeSearch :845-870, beamSearch :606-659,
+ *                           processCandidateNode :661-707 and the distance dispatchers
+ *                           include/flatnav/distances/L2DistanceDispatcher.h:121-126,
+ *                           IPDistanceDispatcher.h:95-100.
+ *   fnv_search_batch_device same, for callers that already keep queries/results in HBM
+ *                           (flatnav::executeInParallel over query rows,
+ *                           include/flatnav/util/Multithreading.h:19-48, becomes the GPU grid).
+ *   out_ndist / out_nhops   Index::_distance_computations, Index.h:83, 689-691, 857-859
+ *                           (kept per query instead of one shared atomic).
+ *   fnv_index_device_buffers / fnv_index_alloc
+ *                           multi-GPU replication: the caller broadcasts the three
+ *                           device buffers with RCCL (one ncclBroadcast each at load,
+ *                           no per-query collective); the reference has no analogue
+ *                           (single process, shared memory).
+ *
+ * Status codes mirror the exception the reference would throw at that point:
+ *   FNV_ERR_INVALID  -> std::invalid_argument (Python ValueError)
+ *   FNV_ERR_RUNTIME  -> std::runtime_error    (Python RuntimeError)
+ */
+#ifndef FLATNAV_HIP_H
+#define FLATNAV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fnv_index_s* fnv_index_t;
+
+enum {
+  FNV_OK = 0,
+  FNV_ERR_INVALID = 1,   /* bad argument (std::invalid_argument in the reference)            */
+  FNV_ERR_RUNTIME = 2,   /* runtime failure (std::runtime_error in the reference)             */
+  FNV_ERR_NO_DEVICE = 3, /* no usable gfx950 device / HIP runtime error                       */
+  FNV_ERR_CAPACITY = 4   /* a per-query on-device structure overflowed its spill area         */
+};
+
+/* flatnav::util::DataType ordinals (include/flatnav/util/Datatype.h:11-24); also the file format's. */
+enum { FNV_DTYPE_UINT8 = 0, FNV_DTYPE_INT8 = 4, FNV_DTYPE_FLOAT32 = 9 };
+/* flatnav::distances::MetricType (include/flatnav/distances/DistanceInterface.h:14). */
+enum { FNV_METRIC_L2 = 0, FNV_METRIC_IP = 1 };
+
+/* Message of the last failing call on this thread (never NULL). */
+const char* fnv_last_error(void);
+
+/* Library / build identification, e.g. "flatnav_hip gfx950 r1". */
+const char* fnv_version(void);
+
+/* Number of visible HIP devices. */
+int fnv_device_count(int* count);
+
+/* Upload a host AoS index blob (exactly the bytes flatnav keeps in _index_memory / writes to its
+ * .bin file after the 60-byte header) to `device` and re-lay it out for the GPU:
+ *   vectors [n_nodes][row_bytes]  (row_bytes = data_size rounded up to 16, zero padded)
+ *   links   [n_nodes][M] uint32   (duplicate ids inside a row are replaced by the node's own id,
+ *                                  which the search treats exactly like the reference treats an
+ *                                  already-visited link)
+ *   labels  [n_nodes] int32
+ * n_nodes is the reference's _cur_num_nodes (NOT max_node_count). The blob is not retained. */
+int fnv_index_upload(const void* aos_blob, uint64_t node_size_bytes, uint64_t data_size_bytes, uint32_t M,
+                     uint64_t n_nodes, int data_type, int metric, uint32_t dim, int device,
+                     fnv_index_t* out);
+
+/* Allocate an EMPTY device index of the given geometry (buffers uninitialised) so that a replica
+ * can be filled by a collective (RCCL broadcast) or a peer copy. */
+int fnv_index_alloc(uint32_t M, uint64_t n_nodes, int data_type, int metric, uint32_t dim, int device,
+                    fnv_index_t* out);
+
+/* Device pointers and byte sizes of the three index buffers: [0]=vectors [1]=links [2]=labels. */
+int fnv_index_device_buffers(fnv_index_t index, void* ptrs[3], uint64_t sizes[3]);
+
+/* info[8] = {data_type, M, row_bytes, n_nodes, dim, metric, device, total_device_bytes}. */
+int fnv_index_info(fnv_index_t index, uint64_t info[8]);
+
+int fnv_index_free(fnv_index_t index);
+
+/* Tuning / test knobs (all optional).  Names:
+ *   "visited_factor"  LDS visited-table slots per unit of beam width (default 32)
+ *   "visited_slots"   force the LDS visited-table size (power of two; 0 = from factor)
+ *   "cand_factor"     LDS candidate-heap entries per unit of beam width (default 3)
+ *   "cand_slots"      force the LDS candidate-heap capacity (0 = from factor)
+ *   "spill_entries"   per-slot HBM spill capacity of the candidate heap (default 16384)
+ *   "blocks_per_cu"   cap resident query slots per CU (0 = occupancy limit) */
+int fnv_set_option(fnv_index_t index, const char* name, int64_t value);
+
+/* Batched search, host buffers.  queries: [nq][dim] elements of the index data type, C-contiguous.
+ * out_dist/out_labels: [nq][K].  Rows with fewer than K reachable results are padded with
+ * (+inf, -1) and reported through out_count[q] (nullable) -- the reference's binding raises
+ * RuntimeError in that case (bindings.cpp:184-189); the host wrapper does the same.
+ * out_ndist / out_nhops (nullable): per-query neighbour distance evaluations and expanded hops. */
+int fnv_search_batch(fnv_index_t index, const void* queries, uint64_t nq, int K, int ef_search,
+                     int num_initializations, float* out_dist, int32_t* out_labels, int32_t* out_count,
+                     uint64_t* out_ndist, uint64_t* out_nhops);
+
+/* Same, but every buffer already lives in this index's device memory and the work is enqueued on
+ * `hip_stream` (a hipStream_t; NULL = the null stream) without synchronising. */
+int fnv_search_batch_device(fnv_index_t index, const void* d_queries, uint64_t nq, int K, int ef_search,
+                            int num_initializations, float* d_out_dist, int32_t* d_out_labels,
+                            int32_t* d_out_count, uint64_t* d_out_ndist, uint64_t* d_out_nhops,
+                            void* hip_stream);
+
+/* Wait for the most recent fnv_search_batch_device launch on this index and report whether any
+ * query hit a capacity limit (FNV_ERR_CAPACITY); fnv_search_batch calls this itself. */
+int fnv_search_status(fnv_index_t index);
+
+/* Duration (ms, HIP events on the launch stream) of the search kernel of the most recent
+ * fnv_search_batch[_device] call on this index; synchronises with that launch. */
+int fnv_last_kernel_ms(fnv_index_t index, float* ms);
+
+/* Launch geometry of the most recent search: geom[6] = {grid_blocks, block_threads, lds_bytes,
+ * blocks_per_cu, visited_slots, cand_slots}. */
+int fnv_last_launch_geometry(fnv_index_t index, uint64_t geom[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLATNAV_HIP_H */

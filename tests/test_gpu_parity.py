@@ -1,0 +1,171 @@
+"""GPU parity: the HIP search path (through the C ABI) against the CPU oracle on the same graphs.
+
+Bar: integer-valued data -> ids, distances, per-query counters BIT-EXACT, including
+tie-heavy inputs; float data -> distances within rtol 1e-5 (stated below), >= 99% of queries with
+identical id lists, recall identical to 3 decimals."""
+import numpy as np
+import pytest
+
+from flatnav_amd import datasets as ds
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hipmod():
+    from flatnav_amd import hip
+
+    assert hip.device_count() >= 1, "no MI355X visible"
+    return hip
+
+
+def _build(oracle_mod, metric, dt, X, M, efc=100):
+    ix = oracle_mod.OracleIndex.create(metric, X.shape[1], X.shape[0], M, dt)
+    ix.add(X, efc)
+    return ix
+
+
+def _upload(hipmod, ix):
+    return hipmod.DeviceIndex.upload(ix.blob(), ix.node_size, ix.data_size, ix.M, ix.cur_nodes, ix.dtype,
+                                     ix.metric, ix.dim)
+
+
+def _assert_exact(o, g):
+    od, ol, ost = o
+    gd, gl, gst = g
+    assert np.array_equal(ost["count"], gst["count"])
+    assert np.array_equal(ol, gl), "ids differ in %d queries" % int((ol != gl).any(axis=1).sum())
+    assert np.array_equal(od.view(np.uint32), gd.view(np.uint32))
+    assert np.array_equal(ost["n_dist"], gst["n_dist"])
+    assert np.array_equal(ost["n_hops"], gst["n_hops"])
+
+
+@pytest.mark.parametrize("ef", [1, 10, 50, 100, 200])
+def test_sift_like_float_exact(oracle_mod, hipmod, ef):
+    X, Q = ds.sift_like(20000, 1000)
+    ix = _build(oracle_mod, "l2", "float32", X, 32)
+    dev = _upload(hipmod, ix)
+    _assert_exact(ix.search(Q, 10, ef, stats=True), dev.search(Q, 10, ef, stats=True))
+
+
+@pytest.mark.parametrize("dim,rng_hi", [(128, 256), (32, 16), (16, 4)])
+def test_uint8_tie_densities_exact(oracle_mod, hipmod, dim, rng_hi):
+    # d=16 / range 4: EVERY query has ties inside its beam -> exercises the libstdc++-exact heaps
+    rng = np.random.default_rng(dim)
+    X = rng.integers(0, rng_hi, (8000, dim)).astype(np.uint8)
+    Q = rng.integers(0, rng_hi, (1000, dim)).astype(np.uint8)
+    ix = _build(oracle_mod, "l2", "uint8", X, 16)
+    dev = _upload(hipmod, ix)
+    for K, ef in ((10, 50), (1, 10), (20, 100)):
+        o = ix.search(Q, K, ef, stats=True)
+        if rng_hi <= 16 and K > 1:
+            assert (np.diff(o[0], axis=1) == 0).any(), "test data should contain ties"
+        _assert_exact(o, dev.search(Q, K, ef, stats=True))
+
+
+@pytest.mark.parametrize("metric,dt", [("l2", "int8"), ("ip", "int8"), ("ip", "uint8"), ("l2", "uint8")])
+def test_integer_dtypes_exact(oracle_mod, hipmod, metric, dt):
+    rng = np.random.default_rng(7)
+    lo, hi = (0, 64) if dt == "uint8" else (-32, 32)
+    X = rng.integers(lo, hi, (6000, 100)).astype(dt)
+    Q = rng.integers(lo, hi, (500, 100)).astype(dt)
+    ix = _build(oracle_mod, metric, dt, X, 16)
+    dev = _upload(hipmod, ix)
+    _assert_exact(ix.search(Q, 10, 64, stats=True), dev.search(Q, 10, 64, stats=True))
+
+
+@pytest.mark.parametrize("dim,M", [(100, 32), (37, 16), (7, 8), (768, 32), (500, 16), (260, 16), (2100, 8)])
+def test_dimension_classes_integer_valued(oracle_mod, hipmod, dim, M):
+    # one case per kernel configuration (row of 16-byte chunks handled by G lanes x CU loads)
+    rng = np.random.default_rng(dim)
+    hi = 256 if dim <= 256 else 64  # keep sums < 2^24
+    n = 4000 if dim <= 768 else 1500
+    X = rng.integers(0, hi, (n, dim)).astype(np.float32)
+    Q = rng.integers(0, hi, (300, dim)).astype(np.float32)
+    for metric in ("l2", "ip"):
+        Xm, Qm = (X, Q) if metric == "l2" else (np.minimum(X, 15), np.minimum(Q, 15))
+        ix = _build(oracle_mod, metric, "float32", Xm, M, efc=64)
+        dev = _upload(hipmod, ix)
+        _assert_exact(ix.search(Qm, 10, 50, stats=True), dev.search(Qm, 10, 50, stats=True))
+
+
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+def test_float_data_within_tolerance(oracle_mod, hipmod, metric):
+    # Float contract: rtol 1e-5 on distances, >= 99% identical id lists, recall equal to 3 decimals.
+    X, Q = ds.randn(20000, 1000, 128, seed=3, normalize=(metric == "ip"))
+    ix = _build(oracle_mod, metric, "float32", X, 32)
+    dev = _upload(hipmod, ix)
+    od, ol = ix.search(Q, 10, 100)
+    gd, gl = dev.search(Q, 10, 100)
+    same = (ol == gl).all(axis=1)
+    assert same.mean() >= 0.99
+    scale = np.maximum(np.abs(od[same]), 1.0)
+    assert (np.abs(od[same] - gd[same]) <= 1e-5 * scale * (128 if metric == "l2" else 1)).all()
+    gt = ds.exact_topk_l2(X, Q, 10) if metric == "l2" else ds.exact_topk_ip(X, Q, 10)
+    assert abs(ds.recall_at_k(ol, gt) - ds.recall_at_k(gl, gt)) < 1e-3
+
+
+def test_small_index_and_short_results(oracle_mod, hipmod):
+    rng = np.random.default_rng(0)
+    X = rng.integers(0, 50, (150, 8)).astype(np.float32)
+    ix = _build(oracle_mod, "l2", "float32", X, 8, efc=50)
+    dev = _upload(hipmod, ix)
+    o = ix.search(X[:40], 200, 300, stats=True)  # K > N: fewer than K results, padded with (+inf, -1)
+    g = dev.search(X[:40], 200, 300, stats=True)
+    _assert_exact(o, g)
+    assert (g[2]["count"] < 200).all() and (g[1][:, -1] == -1).all() and np.isinf(g[0][:, -1]).all()
+    for n_init in (1, 7, 100, 1000):
+        _assert_exact(ix.search(X[:40], 5, 20, n_init, stats=True), dev.search(X[:40], 5, 20, n_init, stats=True))
+
+
+def test_spill_paths_stay_exact(oracle_mod, hipmod):
+    # Force the visited set into its HBM bitmap and the candidate heap into its HBM spill area.
+    X, Q = ds.sift_like(20000, 600)
+    ix = _build(oracle_mod, "l2", "float32", X, 32)
+    o = ix.search(Q, 10, 100, stats=True)
+    dev = _upload(hipmod, ix)
+    dev.set_option("visited_slots", 256)
+    _assert_exact(o, dev.search(Q, 10, 100, stats=True))
+    dev.set_option("visited_slots", 0)
+    dev.set_option("cand_slots", 8)  # kernel raises it to B+1, far below the ~2.6*B admissions
+    _assert_exact(o, dev.search(Q, 10, 100, stats=True))
+    # a second search on the same slots must see clean spill bitmaps
+    dev.set_option("visited_slots", 256)
+    _assert_exact(o, dev.search(Q, 10, 100, stats=True))
+    dev.set_option("spill_entries", 1)
+    with pytest.raises(RuntimeError):
+        dev.search(Q, 10, 100)
+
+
+def test_labels_and_duplicate_links(oracle_mod, hipmod):
+    rng = np.random.default_rng(5)
+    X = rng.integers(0, 256, (3000, 64)).astype(np.float32)
+    labels = rng.permutation(3000).astype(np.int32) * 7 - 5000
+    ix = oracle_mod.OracleIndex.create("l2", 64, 3000, 16)
+    ix.add(X, 64, labels=labels)
+    # plant duplicate ids inside link rows (an .mtx import can produce them, Index.h:219-235);
+    # the reference sees the second copy as already visited
+    blob = ix.blob()
+    rows = blob.reshape(3000, ix.node_size)
+    links = rows[:, ix.data_size:ix.data_size + 4 * 16].copy().view(np.uint32)
+    links[::3, 5] = links[::3, 2]
+    rows[:, ix.data_size:ix.data_size + 4 * 16] = links.view(np.uint8)
+    dev = _upload(hipmod, ix)
+    Q = X[:500] + 1
+    _assert_exact(ix.search(Q, 10, 64, stats=True), dev.search(Q, 10, 64, stats=True))
+
+
+def test_argument_errors(oracle_mod, hipmod):
+    X = np.random.default_rng(1).integers(0, 9, (300, 12)).astype(np.float32)
+    ix = _build(oracle_mod, "l2", "float32", X, 8, efc=30)
+    dev = _upload(hipmod, ix)
+    with pytest.raises(ValueError):
+        dev.search(X[:4], 3, 10, num_initializations=0)  # Index.h:847-849
+    with pytest.raises(ValueError):
+        dev.search(X[:4, :5], 3, 10)
+    with pytest.raises(ValueError):
+        dev.search(X[:4], 0, 10)
+    bad = ix.blob().copy().reshape(300, ix.node_size)
+    bad[0, ix.data_size:ix.data_size + 4] = np.array([10 ** 6], dtype=np.uint32).view(np.uint8)
+    with pytest.raises(RuntimeError):
+        hipmod.DeviceIndex.upload(bad, ix.node_size, ix.data_size, ix.M, 300, "float32", "l2", 12)
