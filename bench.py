@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py -- QPS of the batched flat-NSW k-NN search on MI355X (BASELINE.json configs[1]).
+
+One "step" = one pass of the hot path over one batch: `nq` queries (default 10 000) searched
+against an index resident in HBM (default: the SIFT-1M stand-in of SURVEY.md 8d -- 1M x 128
+float32, integer-valued 0..255, L2, M=32, ef_construction=100, ef_search=100, K=10; SIFT itself
+cannot be downloaded here).  Queries and result buffers live in HBM when the timed region starts.
+
+  python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel
+= beam_search_kernel; achieved = algorithmic bytes per launch / average launch duration from HIP
+events on the launch stream) and, at N=1, `cpu_baseline` (the CPU oracle timed on the host cores).
+Multi-GPU: index replicated with one RCCL broadcast per buffer at load, queries sharded, no
+per-query collective; weak scaling (every rank searches its own nq queries).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+class _DevView:
+    """Expose a raw device pointer to torch through the CUDA array interface."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=1_000_000, help="index size")
+    ap.add_argument("--nq", type=int, default=10_000, help="queries per batch per GPU")
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--M", type=int, default=32)
+    ap.add_argument("--efc", type=int, default=100)
+    ap.add_argument("--ef", type=int, default=100)
+    ap.add_argument("--K", type=int, default=10)
+    ap.add_argument("--build-threads", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="C-ABI option name=value")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import flatnav_amd as flatnav
+    from flatnav_amd import datasets as ds
+    from flatnav_amd import hip
+
+    N, NQ, DIM, M, K, EF = args.n, args.nq, args.dim, args.M, args.K, args.ef
+    hw = os.cpu_count() or 1
+
+    # ---- data: every rank generates the same base stream; queries differ per rank (sharding) ----
+    t0 = time.time()
+    X, Q_all = ds.sift_like(N, NQ * world, dim=DIM)
+    Q = np.ascontiguousarray(Q_all[rank * NQ:(rank + 1) * NQ])
+    log("[rank %d] data %.1fs" % (rank, time.time() - t0))
+
+    # ---- index: rank 0 builds with the product's host builder, uploads, broadcasts ---------------
+    blob_info = None
+    index = None
+    if rank == 0:
+        t0 = time.time()
+        index = flatnav.index.create(distance_type="l2", index_data_type=flatnav.data_type.DataType.float32,
+                                     dim=DIM, dataset_size=N, max_edges_per_node=M)
+        threads = args.build_threads or max(1, min(hw, 192) // (1 if world == 1 else 1))
+        index.set_num_threads(threads)
+        index.add(data=X, ef_construction=args.efc)
+        log("[rank 0] host build: %d nodes, %d threads, %.1fs" % (N, threads, time.time() - t0))
+        t0 = time.time()
+        blob = np.asarray(index._raw_blob())
+        dev = hip.DeviceIndex.upload(blob, index._node_size_bytes, index._data_size_bytes, M, N, "float32", "l2", DIM,
+                                     device=local_rank)
+        log("[rank 0] upload + re-layout to HBM: %.2fs" % (time.time() - t0))
+    else:
+        dev = hip.DeviceIndex.alloc(M, N, "float32", "l2", DIM, device=local_rank)
+    if world > 1:
+        t0 = time.time()
+        for ptr, nbytes in dev.device_buffers():
+            t = torch.as_tensor(_DevView(ptr, nbytes), device="cuda:%d" % local_rank)
+            dist.broadcast(t, src=0)  # RCCL over xGMI, once at load
+        torch.cuda.synchronize()
+        log("[rank %d] index broadcast %.2fs" % (rank, time.time() - t0))
+    for o in args.opt:
+        k, v = o.split("=")
+        dev.set_option(k, int(v))
+
+    # ---- device-resident inputs / outputs ---------------------------------------------------------
+    dq = torch.from_numpy(Q).cuda()
+    d_dist = torch.empty((NQ, K), dtype=torch.float32, device="cuda")
+    d_lab = torch.empty((NQ, K), dtype=torch.int32, device="cuda")
+    d_cnt = torch.empty(NQ, dtype=torch.int32, device="cuda")
+    d_nd = torch.zeros(NQ, dtype=torch.int64, device="cuda")
+    d_nh = torch.zeros(NQ, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream()
+
+    def step():
+        dev.search_device(dq.data_ptr(), NQ, K, EF, 100, d_dist.data_ptr(), d_lab.data_ptr(), d_cnt.data_ptr(),
+                          d_nd.data_ptr(), d_nh.data_ptr(), stream=stream.cuda_stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    dev.status()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(stream)
+        step()
+        b.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev.status()
+    kernel_ms = [a.elapsed_time(b) for a, b in evs]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- algorithmic bytes of one launch from the run's own counters --------------
+    nd = d_nd.cpu().numpy().astype(np.int64)
+    nh = d_nh.cpu().numpy().astype(np.int64)
+    step_nodes = max(1, N // 100)
+    n_scan = (N + step_nodes - 1) // step_nodes
+    bytes_launch = int(((n_scan + nd) * DIM * 4 + nh * M * 4 + K * 4).sum())
+    avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
+    achieved = bytes_launch / avg_kernel_s / 1e9
+
+    out = None
+    if rank == 0:
+        labels = d_lab.cpu().numpy()
+        # recall@10 against exact brute force on the GPU (first 1000 queries of this rank)
+        nrec = min(1000, NQ)
+        xt = torch.from_numpy(X).cuda()
+        qt = dq[:nrec]
+        xn = (xt * xt).sum(1)
+        gt = torch.empty((nrec, K), dtype=torch.int64, device="cuda")
+        for s in range(0, nrec, 250):
+            d2 = xn[None, :] - 2.0 * (qt[s:s + 250] @ xt.T)
+            gt[s:s + 250] = torch.topk(d2, K, dim=1, largest=False).indices
+        recall = ds.recall_at_k(labels[:nrec], gt.cpu().numpy())
+        del xt, xn
+        geom = dev.launch_geometry()
+        total_q = NQ * world * args.steps
+        out = {
+            "metric": "qps_at_recall10_ge_0.95",
+            "value": total_q / elapsed,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "SIFT-1M stand-in (S1 int-lowrank, SURVEY.md 8d): %d x %d float32 L2, M=%d, "
+                            "ef_construction=%d, ef_search=%d, K=%d, %d batched queries per GPU, index in HBM"
+                            % (N, DIM, M, args.efc, EF, K, NQ),
+                "recall_at_10": round(recall, 4),
+                "parallelism": "index replicated x%d, queries sharded" % world,
+                "mean_dist_evals_per_query": float(nd.mean()),
+                "mean_hops_per_query": float(nh.mean()),
+                "launch": geom,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "beam_search_kernel<float, L2, G=8, CU=4>",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": bytes_launch,
+                "avg_kernel_ms": avg_kernel_s * 1e3,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(index, Q, K, EF, hw, labels)
+        del index
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(index, Q, K, EF, hw, gpu_labels):
+    """The CPU oracle (restated reference search, oracle/) on the same graph and queries, all host
+    threads, bounded to roughly 10-20 s.  Also re-checks GPU == CPU ids on the sample."""
+    from oracle import oracle as orc
+
+    orc.build()
+    blob = np.asarray(index._raw_blob())
+    n = int(index._cur_num_nodes)
+    o = orc.OracleIndex.from_blob("l2", "float32", Q.shape[1], n, n, index.max_edges_per_node, blob)
+    kind_note = "oracle port, own AVX2 distance"
+    if o.use_reference_distance(True):
+        kind_note = "oracle port of Index::search driving the reference's own compiled AVX-512 distance kernel (oracle/_ref)"
+    threads = hw
+    o.search(Q[:256], K, EF, threads=threads)  # warm
+    reps, t_used, nq_done = 0, 0.0, 0
+    ol = None
+    while t_used < 8.0 and reps < 50:
+        t0 = time.perf_counter()
+        _, ol = o.search(Q, K, EF, threads=threads)
+        t_used += time.perf_counter() - t0
+        nq_done += len(Q)
+        reps += 1
+    t0 = time.perf_counter()
+    o.search(Q[:2000], K, EF, threads=1)
+    qps1 = 2000 / (time.perf_counter() - t0)
+    same = float((ol == gpu_labels).all(axis=1).mean())
+    return {
+        "value": nq_done / t_used,
+        "unit": "queries/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "%d x the same %d-query batch on %d host threads (%s); single-thread: %.0f queries/s; "
+                  "GPU ids == CPU ids on %.2f%% of queries" % (reps, len(Q), threads, kind_note, qps1, same * 100),
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -32,7 +32,7 @@
 #include <vector>
 
 #include "../../include/flatnav_hip.h"
-#include "stl_exact.h"
+#include <flatnav/util/StlExact.h>
 
 namespace {
 

@@ -1,0 +1,607 @@
+// flatnav/index/Index.h -- host side of the MI355X flat-NSW index (header-only C++17, own code).
+//
+// Keeps the public surface of the reference's flatnav::Index<dist_t, label_t>
+// (include/flatnav/index/Index.h:159-548 of the reference): same constructor, add / addBatch /
+// allocateNode / buildGraphLinks / getGraphOutdegreeTable / search / saveIndex / loadIndex /
+// setNumThreads / getters / resetStats / getIndexSummary, same exceptions, same binary file format.
+//
+// What is different underneath:
+//   * search() and searchBatch() never run on the CPU.  The node store is mirrored to one GPU's
+//     HBM through the C ABI (flatnav_hip.h: fnv_index_upload) and every query is answered by the
+//     gfx950 beam-search kernel (fnv_search_batch).  If the device library or a GPU is missing the
+//     call throws -- there is no CPU fallback.
+//   * Batched search is a first-class call (searchBatch): the reference loops Index::search over
+//     query rows with executeInParallel (bindings.cpp:198-211); here the batch is one kernel launch.
+//   * Index construction (add) stays on the host in this round.  It uses flat-array binary heaps
+//     moved with libstdc++'s exact algorithm (util/StlExact.h), so a single-threaded build yields
+//     the same graph bytes as the reference's std::priority_queue code on tie-free and tied data.
+//   * Per-query counters come back from the device; the shared atomic of the reference
+//     (Index.h:83) is only summed into once per batch.
+#pragma once
+
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <memory>
+#include <mutex>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include <flatnav/distances/DistanceInterface.h>
+#include <flatnav/util/BinaryArchive.h>
+#include <flatnav/util/Datatype.h>
+#include <flatnav/util/Multithreading.h>
+#include <flatnav/util/Reordering.h>
+#include <flatnav/util/StlExact.h>
+#include <flatnav_hip.h>
+
+namespace flatnav {
+
+using flatnav::distances::DistanceInterface;
+using flatnav::distances::MetricType;
+using flatnav::util::DataType;
+
+namespace detail {
+
+// Maps a C-ABI status to the exception the reference throws at the same point.
+inline void throwOnDeviceError(int rc) {
+  if (rc == FNV_OK) return;
+  std::string msg = fnv_last_error();
+  if (rc == FNV_ERR_INVALID) throw std::invalid_argument(msg);
+  throw std::runtime_error(msg);
+}
+
+// Growable array of heap entries with the get/set face StlExact.h expects.
+struct EntryArray {
+  std::vector<fnv_stl::Entry> items;
+  fnv_stl::Entry get(int i) const { return items[static_cast<size_t>(i)]; }
+  void set(int i, fnv_stl::Entry e) {
+    if (static_cast<size_t>(i) >= items.size()) items.resize(static_cast<size_t>(i) + 1);
+    items[static_cast<size_t>(i)] = e;
+  }
+};
+
+// A max-heap keyed on Entry::key only, with exactly std::priority_queue's element moves.
+struct KeyHeap {
+  EntryArray a;
+  int n = 0;
+  void clear() { n = 0; }
+  bool empty() const { return n == 0; }
+  int size() const { return n; }
+  fnv_stl::Entry top() const { return a.items[0]; }
+  void push(float key, uint32_t val) {
+    fnv_stl::heap_push(a, n, fnv_stl::Entry{key, val});
+    ++n;
+  }
+  void pop() {
+    fnv_stl::heap_pop(a, n);
+    --n;
+  }
+};
+
+// One byte per node, test-and-set with backoff; guards a node's link row during construction.
+class NodeLocks {
+  std::unique_ptr<std::atomic<uint8_t>[]> _flags;
+
+ public:
+  void reset(size_t n) {
+    _flags.reset(new std::atomic<uint8_t>[n]);
+    for (size_t i = 0; i < n; ++i) _flags[i].store(0, std::memory_order_relaxed);
+  }
+  void lock(uint32_t node) {
+    while (_flags[node].exchange(1, std::memory_order_acquire)) {
+      while (_flags[node].load(std::memory_order_relaxed)) std::this_thread::yield();
+    }
+  }
+  void unlock(uint32_t node) { _flags[node].store(0, std::memory_order_release); }
+};
+
+struct NodeGuard {
+  NodeLocks& locks;
+  uint32_t node;
+  NodeGuard(NodeLocks& l, uint32_t n) : locks(l), node(n) { locks.lock(node); }
+  ~NodeGuard() { locks.unlock(node); }
+};
+
+// Per-thread working memory of the host builder.
+struct BuildScratch {
+  std::vector<uint32_t> stamp;  // visited epoch per node
+  uint32_t epoch = 0;
+  KeyHeap beam, frontier, prune_pool;
+  std::vector<fnv_stl::Entry> ordered, kept;
+  explicit BuildScratch(size_t nodes) : stamp(nodes, 0u) {}
+  void newEpoch() {
+    if (++epoch == 0) {
+      std::fill(stamp.begin(), stamp.end(), 0u);
+      epoch = 1;
+    }
+  }
+  bool seen(uint32_t node) const { return stamp[node] == epoch; }
+  void mark(uint32_t node) { stamp[node] = epoch; }
+};
+
+}  // namespace detail
+
+template <typename dist_t, typename label_t>
+class Index {
+  static_assert(sizeof(label_t) == 4, "the device path carries labels as 32-bit values");
+
+ public:
+  typedef uint32_t node_id_t;
+  typedef std::pair<float, label_t> dist_label_t;
+
+ private:
+  std::unique_ptr<char[]> _index_memory;
+  size_t _M = 0;
+  size_t _data_size_bytes = 0;
+  size_t _node_size_bytes = 0;  // [data][M links][label], as in the reference (Index.h:61-63, 176)
+  size_t _max_node_count = 0;
+  size_t _cur_num_nodes = 0;
+  std::unique_ptr<DistanceInterface<dist_t>> _distance;
+  uint32_t _num_threads = 1;
+  bool _collect_stats = false;
+  DataType _data_type = DataType::float32;
+  mutable std::atomic<uint64_t> _distance_computations{0};
+  mutable std::atomic<uint64_t> _metric_hops{0};
+
+  // host builder state
+  std::mutex _index_data_guard;
+  detail::NodeLocks _node_locks;
+  std::mutex _scratch_guard;
+  std::vector<std::unique_ptr<detail::BuildScratch>> _scratch_pool;
+
+  // device mirror
+  mutable std::mutex _device_guard;
+  mutable fnv_index_t _device_index = nullptr;
+  mutable bool _device_stale = true;
+  int _device_ordinal = 0;
+
+  Index() = default;
+  Index(const Index&) = delete;
+  Index& operator=(const Index&) = delete;
+
+  // ---- node store ---------------------------------------------------------------------------
+  char* nodeData(node_id_t n) const { return _index_memory.get() + static_cast<uint64_t>(n) * _node_size_bytes; }
+  node_id_t* nodeLinks(node_id_t n) const { return reinterpret_cast<node_id_t*>(nodeData(n) + _data_size_bytes); }
+  label_t* nodeLabel(node_id_t n) const {
+    return reinterpret_cast<label_t*>(nodeData(n) + _data_size_bytes + _M * sizeof(node_id_t));
+  }
+  uint64_t storeBytes() const { return static_cast<uint64_t>(_node_size_bytes) * static_cast<uint64_t>(_max_node_count); }
+
+  void allocateStore() {
+    _index_memory.reset(new char[storeBytes()]());  // zero-filled: saved files are deterministic
+    _node_locks.reset(_max_node_count);
+  }
+
+  template <typename Archive>
+  void serialize(Archive& archive) {
+    // field order = reference Index::serialize (Index.h:134-141) + distance serialize
+    archive(_data_type, _M, _data_size_bytes, _node_size_bytes, _max_node_count, _cur_num_nodes, *_distance);
+    archive(flatnav::util::binary_data(_index_memory.get(), storeBytes()));
+  }
+  friend class flatnav::util::BinaryWriter;
+  friend class flatnav::util::BinaryReader;
+
+  // ---- host builder -------------------------------------------------------------------------
+  std::unique_ptr<detail::BuildScratch> borrowScratch() {
+    std::lock_guard<std::mutex> g(_scratch_guard);
+    if (!_scratch_pool.empty()) {
+      auto s = std::move(_scratch_pool.back());
+      _scratch_pool.pop_back();
+      return s;
+    }
+    return std::make_unique<detail::BuildScratch>(_max_node_count);
+  }
+  void returnScratch(std::unique_ptr<detail::BuildScratch> s) {
+    std::lock_guard<std::mutex> g(_scratch_guard);
+    _scratch_pool.push_back(std::move(s));
+  }
+
+  // Entry node for an insertion: closest of the nodes 0, s, 2s, ... (s = max(1, N / n_init)),
+  // first minimum wins -- the rule of the reference's initializeSearch (Index.h:845-870), which
+  // the GPU kernel applies to queries.
+  node_id_t pickEntry(const void* point, int num_initializations) {
+    if (num_initializations <= 0) throw std::invalid_argument("num_initializations must be greater than 0.");
+    size_t step = _cur_num_nodes / static_cast<size_t>(num_initializations);
+    if (step == 0) step = 1;
+    if (_collect_stats) _distance_computations.fetch_add(static_cast<uint64_t>(num_initializations));
+    float best = std::numeric_limits<float>::max();
+    node_id_t entry = 0;
+    for (size_t node = 0; node < _cur_num_nodes; node += step) {
+      const float d = _distance->distance(point, nodeData(static_cast<node_id_t>(node)), true);
+      if (d < best) {
+        best = d;
+        entry = static_cast<node_id_t>(node);
+      }
+    }
+    return entry;
+  }
+
+  // Beam search used while inserting a point (reference: beamSearch + processCandidateNode,
+  // Index.h:606-707).  Leaves the beam (a max-heap on distance, at most `width` entries) in s.beam.
+  void insertionBeam(const void* point, node_id_t entry, int width, detail::BuildScratch& s) {
+    s.newEpoch();
+    s.beam.clear();
+    s.frontier.clear();
+    const float d0 = _distance->distance(point, nodeData(entry), true);
+    float worst = d0;
+    s.frontier.push(-d0, entry);
+    s.beam.push(d0, entry);
+    s.mark(entry);
+    uint64_t evaluated = 0;
+    while (!s.frontier.empty()) {
+      const fnv_stl::Entry next = s.frontier.top();
+      if (-next.key > worst && s.beam.size() >= width) break;
+      s.frontier.pop();
+      detail::NodeGuard guard(_node_locks, next.val);
+      const node_id_t* links = nodeLinks(next.val);
+      for (size_t i = 0; i < _M; ++i) {
+        const node_id_t nb = links[i];
+        if (s.seen(nb)) continue;
+        s.mark(nb);
+        const float d = _distance->distance(point, nodeData(nb), true);
+        ++evaluated;
+        if (s.beam.size() < width || d < worst) {
+          s.frontier.push(-d, nb);
+          s.beam.push(d, nb);
+          if (s.beam.size() > width) s.beam.pop();
+          worst = s.beam.top().key;
+        }
+      }
+    }
+    if (_collect_stats) _distance_computations.fetch_add(evaluated);
+  }
+
+  // HNSW-style diversity pruning (reference selectNeighbors, Index.h:714-763).  Candidates are
+  // visited closest first, equal distances by DESCENDING id (the pop order of the reference's
+  // std::priority_queue<std::pair<float, node_id_t>> over (-distance, id)); a candidate is kept
+  // unless some already-kept node is strictly closer to it than the query point is.
+  void pruneNeighbors(detail::KeyHeap& heap, int keep, detail::BuildScratch& s) {
+    if (heap.size() < keep) return;
+    s.ordered.assign(heap.a.items.begin(), heap.a.items.begin() + heap.size());
+    std::sort(s.ordered.begin(), s.ordered.end(), [](const fnv_stl::Entry& l, const fnv_stl::Entry& r) {
+      return l.key < r.key || (l.key == r.key && l.val > r.val);
+    });
+    s.kept.clear();
+    for (const fnv_stl::Entry& c : s.ordered) {
+      if (static_cast<int>(s.kept.size()) >= keep) break;
+      bool diverse = true;
+      for (const fnv_stl::Entry& k : s.kept) {
+        if (_distance->distance(nodeData(k.val), nodeData(c.val)) < c.key) {
+          diverse = false;
+          break;
+        }
+      }
+      if (diverse) s.kept.push_back(c);
+    }
+    heap.clear();
+    for (const fnv_stl::Entry& k : s.kept) heap.push(k.key, k.val);
+  }
+
+  // Wire the new node to its selected neighbours and add back-links (reference connectNeighbors,
+  // Index.h:765-834): a back-link takes the neighbour's first free (self-loop) slot, otherwise the
+  // neighbour's row is re-pruned over {old links} + {new node}.
+  void linkNeighbors(detail::KeyHeap& selected, node_id_t new_id, detail::BuildScratch& s) {
+    detail::NodeGuard own(_node_locks, new_id);
+    node_id_t* new_links = nodeLinks(new_id);
+    size_t slot = 0;
+    while (!selected.empty()) {
+      const node_id_t nb = selected.top().val;
+      new_links[slot++] = nb;
+      {
+        detail::NodeGuard theirs(_node_locks, nb);
+        node_id_t* nb_links = nodeLinks(nb);
+        size_t free_slot = _M;
+        for (size_t j = 0; j < _M; ++j)
+          if (nb_links[j] == nb) {
+            free_slot = j;
+            break;
+          }
+        if (free_slot < _M) {
+          nb_links[free_slot] = new_id;
+        } else {
+          detail::KeyHeap& pool = s.prune_pool;
+          pool.clear();
+          pool.push(_distance->distance(nodeData(nb), nodeData(new_id)), new_id);
+          for (size_t j = 0; j < _M; ++j)
+            if (nb_links[j] != nb) pool.push(_distance->distance(nodeData(nb), nodeData(nb_links[j])), nb_links[j]);
+          pruneNeighbors(pool, static_cast<int>(_M), s);
+          size_t j = 0;
+          while (!pool.empty()) {
+            nb_links[j++] = pool.top().val;
+            pool.pop();
+          }
+          while (j < _M) nb_links[j++] = nb;
+        }
+      }
+      selected.pop();
+    }
+  }
+
+  void markDeviceStale() { _device_stale = true; }
+
+  void ensureDevice() const {
+    if (_device_index && !_device_stale) return;
+    if (_device_index) {
+      fnv_index_free(_device_index);
+      _device_index = nullptr;
+    }
+    const int metric = const_cast<Index*>(this)->_distance->metricType() == MetricType::L2 ? FNV_METRIC_L2 : FNV_METRIC_IP;
+    detail::throwOnDeviceError(fnv_index_upload(_index_memory.get(), _node_size_bytes, _data_size_bytes,
+                                                static_cast<uint32_t>(_M), _cur_num_nodes,
+                                                static_cast<int>(_data_type), metric,
+                                                static_cast<uint32_t>(const_cast<Index*>(this)->_distance->dimension()),
+                                                _device_ordinal, &_device_index));
+    _device_stale = false;
+  }
+
+ public:
+  // Reference constructor (Index.h:159-179).
+  Index(std::unique_ptr<DistanceInterface<dist_t>> dist, int dataset_size, int max_edges_per_node,
+        bool collect_stats = false, DataType data_type = DataType::float32)
+      : _M(static_cast<size_t>(max_edges_per_node)),
+        _max_node_count(static_cast<size_t>(dataset_size)),
+        _distance(std::move(dist)),
+        _collect_stats(collect_stats),
+        _data_type(data_type) {
+    _data_size_bytes = _distance->dataSize();
+    _node_size_bytes = _data_size_bytes + sizeof(node_id_t) * _M + sizeof(label_t);
+    allocateStore();
+  }
+
+  ~Index() {
+    if (_device_index) fnv_index_free(_device_index);
+  }
+
+  // ---- GPU placement (new) ------------------------------------------------------------------
+  void setDevice(int ordinal) {
+    std::lock_guard<std::mutex> g(_device_guard);
+    if (ordinal != _device_ordinal) {
+      _device_ordinal = ordinal;
+      markDeviceStale();
+    }
+  }
+  int device() const { return _device_ordinal; }
+  // Push pending host-side changes to HBM now (otherwise done lazily by the next search).
+  void syncDevice() {
+    std::lock_guard<std::mutex> g(_device_guard);
+    ensureDevice();
+  }
+  // The C-ABI handle of the device mirror (valid until the next mutation); for callers that drive
+  // fnv_search_batch_device on their own buffers / streams.
+  fnv_index_t deviceHandle() {
+    std::lock_guard<std::mutex> g(_device_guard);
+    ensureDevice();
+    return _device_index;
+  }
+
+  // ---- graph import (reference Index.h:187-251) ----------------------------------------------
+  void buildGraphLinks(const std::string& mtx_filename) {
+    std::ifstream input(mtx_filename);
+    if (!input.is_open()) throw std::runtime_error("Unable to open file for reading: " + mtx_filename);
+    std::string line;
+    while (std::getline(input, line))
+      if (line.empty() || line[0] != '%') break;
+    std::istringstream header(line);
+    long long rows = 0, cols = 0, edges = 0;
+    header >> rows >> cols >> edges;
+    if (static_cast<size_t>(cols) != _max_node_count)
+      throw std::runtime_error("Number of vertices in the mtx file does not match the size allocated for the index.");
+    if (static_cast<size_t>(edges) != _M)
+      throw std::runtime_error("Number of edges in the mtx file does not match the number of links per node.");
+    long long u, v;
+    while (input >> u >> v) {
+      --u;  // MatrixMarket is 1-based
+      --v;
+      node_id_t* links = nodeLinks(static_cast<node_id_t>(u));
+      for (size_t i = 0; i < _M; ++i)
+        if (links[i] == static_cast<node_id_t>(u)) {  // first free slot
+          links[i] = static_cast<node_id_t>(v);
+          break;
+        }
+    }
+    markDeviceStale();
+  }
+
+  std::vector<std::vector<uint32_t>> getGraphOutdegreeTable() {
+    std::vector<std::vector<uint32_t>> table(_cur_num_nodes);
+    for (node_id_t node = 0; node < _cur_num_nodes; ++node) {
+      const node_id_t* links = nodeLinks(node);
+      for (size_t i = 0; i < _M; ++i)
+        if (links[i] != node) table[node].push_back(links[i]);
+    }
+    return table;
+  }
+
+  // ---- construction (reference Index.h:262-378) ----------------------------------------------
+  void allocateNode(void* data, label_t& label, node_id_t& new_node_id) {
+    new_node_id = static_cast<node_id_t>(_cur_num_nodes);
+    _distance->transformData(nodeData(new_node_id), data);
+    *nodeLabel(new_node_id) = label;
+    std::fill_n(nodeLinks(new_node_id), _M, new_node_id);  // self-loop == empty slot
+    ++_cur_num_nodes;
+    markDeviceStale();
+  }
+
+  template <typename data_type>
+  void addBatch(void* data, std::vector<label_t>& labels, int ef_construction, int num_initializations = 100) {
+    if (num_initializations <= 0) throw std::invalid_argument("num_initializations must be greater than 0.");
+    const uint32_t total = static_cast<uint32_t>(labels.size());
+    const uint64_t dim = _distance->dimension();
+    auto insertRow = [&](uint32_t row) {
+      void* vec = static_cast<data_type*>(data) + static_cast<uint64_t>(row) * dim;
+      label_t label = labels[row];
+      this->add(vec, label, ef_construction, num_initializations);
+    };
+    if (_num_threads == 1) {
+      for (uint32_t row = 0; row < total; ++row) insertRow(row);
+      return;
+    }
+    flatnav::executeInParallel(0, total, _num_threads, insertRow);
+  }
+
+  void add(void* data, label_t& label, int ef_construction, int num_initializations) {
+    if (_cur_num_nodes >= _max_node_count)
+      throw std::runtime_error(
+          "Maximum number of nodes reached. Consider increasing the `max_node_count` parameter to create a larger "
+          "index.");
+    node_id_t entry, new_id;
+    {
+      std::lock_guard<std::mutex> g(_index_data_guard);
+      entry = pickEntry(data, num_initializations);
+      allocateNode(data, label, new_id);
+    }
+    if (new_id == 0) return;
+    auto scratch = borrowScratch();
+    insertionBeam(data, entry, ef_construction, *scratch);
+    pruneNeighbors(scratch->beam, std::max(static_cast<int>(_M / 2), 1), *scratch);
+    linkNeighbors(scratch->beam, new_id, *scratch);
+    returnScratch(std::move(scratch));
+  }
+
+  // ---- search: always on the GPU -------------------------------------------------------------
+  // Batched search (new; what bindings.cpp:161-228 does with a host loop).  queries = nq rows of
+  // `dimension` elements of the index data type.  out_count may be null.  Returns nothing; rows
+  // with fewer than K reachable results are padded with (+inf, -1) and flagged in out_count.
+  void searchBatch(const void* queries, uint64_t nq, int K, int ef_search, int num_initializations, float* out_dist,
+                   label_t* out_labels, int32_t* out_count = nullptr) {
+    if (num_initializations <= 0) throw std::invalid_argument("num_initializations must be greater than 0.");
+    std::lock_guard<std::mutex> g(_device_guard);
+    ensureDevice();
+    std::vector<uint64_t> ndist;
+    if (_collect_stats) ndist.resize(nq);
+    detail::throwOnDeviceError(fnv_search_batch(_device_index, queries, nq, K, ef_search, num_initializations, out_dist,
+                                                reinterpret_cast<int32_t*>(out_labels), out_count,
+                                                _collect_stats ? ndist.data() : nullptr, nullptr));
+    if (_collect_stats) {
+      // reference accounting: + num_initializations per query (Index.h:857-859), + 1 per neighbour
+      // evaluation (Index.h:689-691)
+      uint64_t total = static_cast<uint64_t>(num_initializations) * nq;
+      for (uint64_t v : ndist) total += v;
+      _distance_computations.fetch_add(total);
+    }
+  }
+
+  // Reference Index::search (Index.h:387-409): up to K (distance, label) pairs, ascending.
+  std::vector<dist_label_t> search(const void* query, const int K, int ef_search, int num_initializations = 100) {
+    std::vector<float> dist(static_cast<size_t>(std::max(K, 0)));
+    std::vector<label_t> labels(static_cast<size_t>(std::max(K, 0)));
+    int32_t count = 0;
+    searchBatch(query, 1, K, ef_search, num_initializations, dist.data(), labels.data(), &count);
+    std::vector<dist_label_t> results;
+    results.reserve(static_cast<size_t>(count));
+    for (int i = 0; i < count; ++i) results.emplace_back(dist[static_cast<size_t>(i)], labels[static_cast<size_t>(i)]);
+    return results;
+  }
+
+  // ---- reordering (reference Index.h:412-440, 872-926) ---------------------------------------
+  void doGraphReordering(const std::vector<std::string>& reordering_methods) {
+    for (const auto& method : reordering_methods) {
+      auto table = getGraphOutdegreeTable();
+      std::vector<node_id_t> perm;
+      if (method == "gorder") perm = util::gOrder<node_id_t>(table, 5);
+      else if (method == "rcm") perm = util::rcmOrder<node_id_t>(table);
+      else throw std::invalid_argument("Invalid reordering method: " + method);
+      relabel(perm);
+    }
+  }
+  void reorderGOrder(const int window_size = 5) {
+    auto table = getGraphOutdegreeTable();
+    relabel(util::gOrder<node_id_t>(table, window_size));
+  }
+  void reorderRCM() {
+    auto table = getGraphOutdegreeTable();
+    relabel(util::rcmOrder<node_id_t>(table));
+  }
+
+  // ---- persistence (reference Index.h:442-490) -----------------------------------------------
+  static std::unique_ptr<Index<dist_t, label_t>> loadIndex(const std::string& filename) {
+    std::ifstream stream(filename, std::ios::binary);
+    if (!stream.is_open()) throw std::runtime_error("Unable to open file for reading: " + filename);
+    flatnav::util::BinaryReader archive(stream);
+    std::unique_ptr<Index<dist_t, label_t>> index(new Index<dist_t, label_t>());
+    std::unique_ptr<DistanceInterface<dist_t>> dist = std::make_unique<dist_t>();
+    archive(index->_data_type, index->_M, index->_data_size_bytes, index->_node_size_bytes, index->_max_node_count,
+            index->_cur_num_nodes, *dist);
+    if (index->_node_size_bytes != index->_data_size_bytes + sizeof(node_id_t) * index->_M + sizeof(label_t) ||
+        index->_cur_num_nodes > index->_max_node_count)
+      throw std::runtime_error("Corrupt index header: " + filename);
+    index->_distance = std::move(dist);
+    index->_num_threads = std::max<uint32_t>(1, std::thread::hardware_concurrency() / 2);
+    index->allocateStore();
+    archive(flatnav::util::binary_data(index->_index_memory.get(), index->storeBytes()));
+    return index;
+  }
+
+  void saveIndex(const std::string& filename) {
+    std::ofstream stream(filename, std::ios::binary);
+    if (!stream.is_open()) throw std::runtime_error("Unable to open file for writing: " + filename);
+    flatnav::util::BinaryWriter archive(stream);
+    archive(*this);
+  }
+
+  // ---- knobs and getters (reference Index.h:492-548) -----------------------------------------
+  inline void setNumThreads(uint32_t num_threads) {
+    if (num_threads == 0 || num_threads > std::thread::hardware_concurrency())
+      throw std::invalid_argument(
+          "Number of threads must be greater than 0 and less than or equal to the number of hardware threads.");
+    _num_threads = num_threads;
+  }
+  inline uint32_t getNumThreads() const { return _num_threads; }
+  inline uint64_t getTotalIndexMemory() const { return storeBytes(); }
+  inline uint64_t mutexesAllocatedMemory() const { return static_cast<uint64_t>(_max_node_count); }
+  inline uint64_t visitedSetPoolAllocatedMemory() const {
+    return static_cast<uint64_t>(_scratch_pool.size()) * _max_node_count * sizeof(uint32_t);
+  }
+  inline size_t maxEdgesPerNode() const { return _M; }
+  inline size_t dataSizeBytes() const { return _data_size_bytes; }
+  inline size_t nodeSizeBytes() const { return _node_size_bytes; }
+  inline size_t maxNodeCount() const { return _max_node_count; }
+  inline size_t currentNumNodes() const { return _cur_num_nodes; }
+  inline size_t dataDimension() const { return _distance->dimension(); }
+  inline uint64_t distanceComputations() const { return _distance_computations.load(); }
+  inline DataType getDataType() const { return _data_type; }
+  inline const char* rawIndexMemory() const { return _index_memory.get(); }
+
+  void resetStats() {
+    _distance_computations = 0;
+    _metric_hops = 0;
+  }
+
+  void getIndexSummary() const {
+    std::cout << "\nIndex Parameters\n-----------------------------\n"
+              << "max_edges_per_node (M): " << _M << "\n"
+              << "data_size_bytes: " << _data_size_bytes << "\n"
+              << "node_size_bytes: " << _node_size_bytes << "\n"
+              << "max_node_count: " << _max_node_count << "\n"
+              << "cur_num_nodes: " << _cur_num_nodes << "\n"
+              << std::flush;
+    _distance->getSummary();
+  }
+
+ private:
+  // Apply a permutation (perm[old] = new id): rewrite every link, then move the node records with
+  // one gather into a fresh store (reference relabel(), Index.h:872-926, permutes in place).
+  void relabel(const std::vector<node_id_t>& perm) {
+    if (perm.size() != _cur_num_nodes) throw std::runtime_error("reordering permutation has the wrong size");
+    for (node_id_t n = 0; n < _cur_num_nodes; ++n) {
+      node_id_t* links = nodeLinks(n);
+      for (size_t m = 0; m < _M; ++m) links[m] = perm[links[m]];
+    }
+    std::unique_ptr<char[]> fresh(new char[storeBytes()]());
+    for (node_id_t n = 0; n < _cur_num_nodes; ++n)
+      std::memcpy(fresh.get() + static_cast<uint64_t>(perm[n]) * _node_size_bytes, nodeData(n), _node_size_bytes);
+    _index_memory = std::move(fresh);
+    markDeviceStale();
+  }
+};
+
+}  // namespace flatnav

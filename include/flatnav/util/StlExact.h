@@ -1,4 +1,4 @@
-// stl_exact.h -- operation-for-operation restatement of the libstdc++ binary
+// flatnav/util/StlExact.h -- operation-for-operation restatement of the libstdc++ binary
 // heap and introsort routines that the reference's search leans on, written so
 // the SAME code runs on the host (unit-tested against the real std:: calls) and
 // inside the HIP kernel.

@@ -10,7 +10,7 @@
 #include <utility>
 #include <vector>
 
-#include "../flatnav_amd/csrc/stl_exact.h"
+#include "../include/flatnav/util/StlExact.h"
 
 typedef std::pair<float, uint32_t> P;
 struct CompareByFirst {
