@@ -30,16 +30,18 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, defines=(), out: str | None = None) -> str:
+    out = out or LIB
+    if not force and out == LIB and not needs_build():
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")] + SOURCES + ["-o", LIB]
+           "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")] + ["-D" + d for d in defines] + SOURCES + [
+               "-o", out]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":

@@ -56,6 +56,7 @@ struct SearchParams {
   int32_t* status;          // sticky error flag for the whole launch
   uint32_t* ovf_bitmap;     // [nslots][bitmap_words] visited-set spill (all zero between queries)
   unsigned long long* cand_spill;  // [nslots][spill_entries]
+  unsigned long long* phase_cycles;  // [16] profiling build only (FNV_PHASE_TIMING), else null
   uint64_t n_nodes;
   uint32_t nq, M, dim, row_bytes, nchunks, q_chunks;
   int K, B;
@@ -78,14 +79,20 @@ __device__ __forceinline__ fnv_stl::Entry unpack(unsigned long long v) {
   return e;
 }
 
+// The array starts 8 bytes past a 16-byte boundary, so the two children (2i+1, 2i+2) of any node
+// form one aligned 16-byte pair: a single ds_read_b128 fetches both.
 struct LdsHeap {
   unsigned long long* p;
   __device__ __forceinline__ fnv_stl::Entry get(int i) const { return unpack(p[i]); }
   __device__ __forceinline__ void set(int i, fnv_stl::Entry e) { p[i] = pack(e); }
+  __device__ __forceinline__ bool leftChildWins(int i) const {  // key[2i+2] < key[2i+1]
+    const uint4 c = *reinterpret_cast<const uint4*>(p + 2 * i + 1);
+    return __uint_as_float(c.z) < __uint_as_float(c.x);
+  }
 };
 
-// Candidates heap: first `cap` entries in LDS, the rest in a per-slot HBM spill area.  Only lane 0
-// ever touches it, so plain program order keeps it coherent.
+// Candidates heap: first `cap` entries in LDS, the rest in a per-slot HBM spill area (rare; the
+// kernel fences around operations that reach into it).
 struct CandHeap {
   unsigned long long* p;
   unsigned long long* spill;
@@ -95,7 +102,181 @@ struct CandHeap {
     if (i < cap) p[i] = pack(e);
     else spill[i - cap] = pack(e);
   }
+  __device__ __forceinline__ bool leftChildWins(int i) const { return get(2 * i + 2).key < get(2 * i + 1).key; }
 };
+
+// ---------------------------------------------------------------------------------------------
+// Phase timing (profiling builds only: -DFNV_PHASE_TIMING).  mark(i) charges the shader cycles
+// since the previous mark to phase i, after draining outstanding memory operations so that a phase
+// owns its own latency.  In product builds the struct is empty and every call folds away.
+// ---------------------------------------------------------------------------------------------
+constexpr int NPHASE = 16;
+#ifdef FNV_PHASE_TIMING
+struct PhaseTimer {
+  unsigned long long t[NPHASE];
+  unsigned long long last;
+  __device__ __forceinline__ void start() {
+    for (int i = 0; i < NPHASE; i++) t[i] = 0;
+    last = clock64();
+  }
+  __device__ __forceinline__ void mark(int i) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    unsigned long long n = clock64();
+    t[i] += n - last;
+    last = n;
+  }
+  __device__ __forceinline__ void flush(unsigned long long* out, int lane) {
+    if (lane == 0 && out)
+      for (int i = 0; i < NPHASE; i++) atomicAdd(&out[i], t[i]);
+  }
+};
+#else
+struct PhaseTimer {
+  __device__ __forceinline__ void start() {}
+  __device__ __forceinline__ void mark(int) {}
+  __device__ __forceinline__ void flush(unsigned long long*, int) {}
+};
+#endif
+#define PH_DECL PhaseTimer ph; ph.start();
+#define PH_MARK(i) ph.mark(i)
+#define PH_FLUSH ph.flush(p.phase_cycles, lane)
+
+// ---------------------------------------------------------------------------------------------
+// Wave-cooperative forms of the two libstdc++ heap operations (same element moves as
+// fnv_stl::heap_push / heap_pop in flatnav/util/StlExact.h, which tests/ check against the real
+// std::priority_queue), executed by all 64 lanes with O(1) LDS round trips instead of one per level.
+//
+//  push(n, v): the hole climbs the ancestor chain a_k = ((n+1) >> k) - 1 of index n while
+//    heap[a_k].key < v.key.  All ancestors are read at once (lane j reads a_{j+1}); a ballot of the
+//    comparisons gives t = length of the leading run of "true"; lanes j < t move their ancestor one
+//    level down, lane t stores v.
+//  pop(n): __adjust_heap walks the hole from the root to a leaf always taking the larger child
+//    (right unless right < left), then sifts the former last element v back up.  Which child wins at
+//    node i depends only on the array, so every internal node is judged in parallel (ballot ->
+//    one 64-bit mask per 64 nodes, parked in lane r of two VGPRs), the root-to-leaf path is then a
+//    scalar walk over those masks (v_readlane, no memory), the path's values are fetched in one
+//    parallel read, the sift-up length comes from one more ballot, and the surviving moves are one
+//    parallel write.  Moves that the sequential code does and then undoes are simply not performed.
+// All lanes must call these with wave-uniform arguments.
+// ---------------------------------------------------------------------------------------------
+// Ordering between the lanes of ONE wave: the LDS executes a wave's instructions in issue order,
+// so a later read by any lane sees an earlier write by any other lane; only the compiler must be
+// kept from reordering the accesses (it reasons per thread).  No hardware wait is emitted.
+__device__ __forceinline__ void wave_sync() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <class H>
+__device__ __forceinline__ void coop_push(H& h, int n, fnv_stl::Entry v, int lane, PhaseTimer& ph, int phbase) {
+  n = __builtin_amdgcn_readfirstlane(n);
+  v.key = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.key)));
+  v.val = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.val);
+  const uint32_t m1 = (uint32_t)n + 1u;
+  const int depth = 31 - __clz((int)m1);  // number of ancestors of index n
+  fnv_stl::Entry anc = v;
+  bool up = false;
+  if (lane < depth) {
+    anc = h.get((int)(m1 >> (lane + 1)) - 1);
+    up = anc.key < v.key;
+  }
+  const unsigned long long run = __ballot(up);
+  const int t = __ffsll((long long)~run) - 1;  // lanes >= depth vote false, so t <= depth
+  if (lane < t) h.set((int)(m1 >> lane) - 1, anc);
+  if (lane == t) h.set((int)(m1 >> t) - 1, v);
+  wave_sync();
+  ph.mark(phbase);
+}
+
+template <class H>
+__device__ __forceinline__ void coop_pop(H& h, int n, int lane, PhaseTimer& ph, int phbase) {
+  n = __builtin_amdgcn_readfirstlane(n);
+  if (n <= 1) return;  // std::pop_heap does nothing for a single element
+  if (n > 8192) {      // more two-child nodes than 64 lanes x 64 mask bits: plain sequential form
+    if (lane == 0) fnv_stl::heap_pop(h, n);
+    wave_sync();
+    return;
+  }
+  const int len = n - 1;
+  const fnv_stl::Entry v_raw = h.get(len);  // same address in all lanes (broadcast); used in phase 3
+  const fnv_stl::Entry top = h.get(0);
+  const int two = (len - 1) / 2;  // nodes [0, two) have two children
+  // phase 1: for every two-child node, does the RIGHT child win (i.e. NOT right.key < left.key)?
+  // phase 2: walk root -> leaf in 1-based numbering (node m = index + 1; children 2m, 2m+1): the
+  // next node is (m << 1) | right_wins(m), so after L steps `m` spells the whole path: the node at
+  // depth j is m >> (L - j).  Every lane then derives its own path entry from that one scalar.
+  uint32_t m = 1;  // 1-based position of the hole
+  int L = 0;
+  const uint32_t two1 = (uint32_t)two;  // nodes with 1-based number <= two have two children
+  if (two <= WAVE - 1) {
+    // <= 63 two-child nodes (heaps of <= 128 entries): one scalar mask, indexed by 1-based number
+    const unsigned long long rw = __ballot(lane >= 1 && lane <= two && !h.leftChildWins(lane - 1));
+    ph.mark(phbase);
+    while (m <= two1) {
+      m = (m << 1) | (uint32_t)((rw >> m) & 1ull);
+      L++;
+    }
+  } else if (two <= 4 * WAVE) {
+    // <= 256 two-child nodes (heaps of <= 514 entries): four scalar masks, indexed by 0-based number
+    unsigned long long r0 = __ballot(lane < two && !h.leftChildWins(lane)), r1 = 0, r2 = 0, r3 = 0;
+    r1 = __ballot(WAVE + lane < two && !h.leftChildWins(WAVE + lane));
+    if (two > 2 * WAVE) r2 = __ballot(2 * WAVE + lane < two && !h.leftChildWins(2 * WAVE + lane));
+    if (two > 3 * WAVE) r3 = __ballot(3 * WAVE + lane < two && !h.leftChildWins(3 * WAVE + lane));
+    ph.mark(phbase);
+    while (m <= two1) {
+      const uint32_t i0 = m - 1, w = i0 >> 6;
+      const unsigned long long rw = w == 0 ? r0 : w == 1 ? r1 : w == 2 ? r2 : r3;
+      m = (m << 1) | (uint32_t)((rw >> (i0 & 63)) & 1ull);
+      L++;
+    }
+  } else {
+    int mlo = 0, mhi = 0;  // lane r keeps the mask of nodes [64r, 64r+64)
+    for (int r = 0; r * WAVE < two; r++) {
+      const int node = r * WAVE + lane;
+      const unsigned long long rw = __ballot(node < two && !h.leftChildWins(node));
+      if (lane == r) {
+        mlo = (int)(uint32_t)rw;
+        mhi = (int)(uint32_t)(rw >> 32);
+      }
+    }
+    ph.mark(phbase);
+    while (m <= two1) {
+      const uint32_t i0 = m - 1, w = i0 >> 6;
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(mlo, (int)w);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane(mhi, (int)w);
+      const unsigned long long rw = ((unsigned long long)hi << 32) | lo;
+      m = (m << 1) | (uint32_t)((rw >> (i0 & 63)) & 1ull);
+      L++;
+    }
+  }
+  if ((len & 1) == 0 && m - 1 == two1) {  // the one node with a single (left) child, stl_heap.h:235-241
+    m = m << 1;
+    L++;
+  }
+  // lane j (j <= L) owns the path node at depth j
+  const int sh = L - lane;
+  const int my_p = sh >= 0 ? (int)(m >> sh) - 1 : 0;
+  const int my_next = sh >= 1 ? (int)(m >> (sh - 1)) - 1 : 0;
+  ph.mark(phbase + 1);
+  // phase 3: values on the path, sift-up length, surviving moves
+  fnv_stl::Entry v;
+  v.key = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v_raw.key)));
+  v.val = (uint32_t)__builtin_amdgcn_readfirstlane((int)v_raw.val);
+  fnv_stl::Entry val = v;
+  bool back = false;
+  if (lane < L) {
+    val = h.get(my_next);
+    back = val.key < v.key;  // this moved-up element would be pushed back down by the sift-up
+  }
+  const unsigned long long fail = ~__ballot(back) & ((1ull << L) - 1ull);  // L <= 31
+  const int jf = fail ? 63 - __clzll((long long)fail) : -1;  // deepest level whose move survives
+  if (lane <= jf) h.set(my_p, val);
+  if (lane == jf + 1) h.set(my_p, v);
+  if (lane == 0) h.set(len, top);  // std::pop_heap parks the old top in the vacated slot
+  wave_sync();
+  ph.mark(phbase + 2);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Cross-lane sums over aligned groups of G lanes (DPP inside a 16-lane row, bpermute above).
@@ -291,8 +472,9 @@ __global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p)
   const int lane = threadIdx.x;
   uint4* qlds = reinterpret_cast<uint4*>(smem + p.off_q);
   LdsHeap nbr{reinterpret_cast<unsigned long long*>(smem + p.off_nbr)};
-  CandHeap cand{reinterpret_cast<unsigned long long*>(smem + p.off_cand),
-                p.cand_spill + (uint64_t)blockIdx.x * p.spill_entries, (int)p.cand_slots};
+  LdsHeap cand{reinterpret_cast<unsigned long long*>(smem + p.off_cand)};  // while everything fits in LDS
+  CandHeap cand_big{reinterpret_cast<unsigned long long*>(smem + p.off_cand),
+                    p.cand_spill + (uint64_t)blockIdx.x * p.spill_entries, (int)p.cand_slots};
   uint32_t* vis = reinterpret_cast<uint32_t*>(smem + p.off_vis);
   uint32_t* stage_ids = reinterpret_cast<uint32_t*>(smem + p.off_stage_ids);
   float* stage_d = reinterpret_cast<float*>(smem + p.off_stage_d);
@@ -307,6 +489,7 @@ __global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p)
     if (lane == 0) qi = (int)atomicAdd(p.dispenser, 1u);
     qi = rfl(qi);
     if ((uint32_t)qi >= p.nq) break;
+    PH_DECL
 
     // ---- stage the query (zero padded) and reset the visited table --------------------------
     {
@@ -318,6 +501,7 @@ __global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p)
       for (uint32_t i = lane; i < p.vis_slots / 4; i += WAVE) v4[i] = make_uint4(EMPTY_ID, EMPTY_ID, EMPTY_ID, EMPTY_ID);
     }
     __syncthreads();
+    PH_MARK(0);
 
     // ---- entry-point selection (Index.h:845-870): argmin over nodes 0, s, 2s, ... -----------
     float best_d = std::numeric_limits<float>::max();
@@ -347,6 +531,7 @@ __global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p)
       }
     }
     const uint32_t entry = best_j * p.scan_step;
+    PH_MARK(1);
 
     // ---- beam search (Index.h:606-707) -------------------------------------------------------
     int nbr_n = 1, cand_n = 1;
@@ -363,24 +548,28 @@ __global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p)
     __syncthreads();
 
     while (true) {
-      int node = -1;
-      if (lane == 0 && cand_n > 0) {
-        fnv_stl::Entry top = cand.get(0);
-        if (!(-top.key > max_dist && nbr_n >= B)) {  // Index.h:630
-          fnv_stl::heap_pop(cand, cand_n);
-          node = (int)top.val;
-        }
+      if (cand_n <= 0) break;
+      const fnv_stl::Entry ctop = cand.get(0);  // same address in every lane: LDS broadcast
+      const float ctop_d = -rfl(ctop.key);
+      if (ctop_d > max_dist && nbr_n >= B) break;  // Index.h:630
+      const int node = rfl((int)ctop.val);
+      if (cand_n <= (int)p.cand_slots) {
+        coop_pop(cand, cand_n, lane, ph, 8);
+      } else {  // part of the heap lives in the HBM spill area
+        __threadfence_block();
+        coop_pop(cand_big, cand_n, lane, ph, 8);
+        __threadfence_block();
       }
-      node = rfl(node);
-      if (node < 0) break;
       cand_n--;
       n_hops++;
+      PH_MARK(2);
 
       for (int m0 = 0; m0 < M; m0 += WAVE) {
         if (!ovf && vis_count + WAVE > p.vis_limit) ovf = true;
         const bool act = m0 + lane < M;
         uint32_t id = EMPTY_ID;
         if (act) id = p.links[(uint64_t)(uint32_t)node * p.M + m0 + lane];
+        PH_MARK(3);
         bool isnew = false;
         if (act) {
           if (!ovf) {
@@ -396,10 +585,12 @@ __global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p)
         if (isnew) stage_ids[__popcll(newmask & ((1ull << lane) - 1ull))] = id;  // keeps link order
         vis_count += n;
         __syncthreads();
+        PH_MARK(4);
         if (n == 0) continue;
         compute_dists<T, METRIC, G, CU>(p, qlds, stage_ids, n, stage_d, lane);
         __syncthreads();
         n_dist += n;
+        PH_MARK(5);
 
         float d = 0.f;
         uint32_t cid = 0;
@@ -421,23 +612,27 @@ __global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p)
               pm = 0;
               break;
             }
-            float md = 0.f;
-            if (lane == 0) {
-              fnv_stl::heap_push(cand, cand_n, fnv_stl::Entry{-di, idi});
-              fnv_stl::heap_push(nbr, nbr_n, fnv_stl::Entry{di, idi});
-              if (nbr_n + 1 > B) fnv_stl::heap_pop(nbr, nbr_n + 1);
-              md = nbr.get(0).key;
+            if (cand_n < (int)p.cand_slots) {
+              coop_push(cand, cand_n, fnv_stl::Entry{-di, idi}, lane, ph, 11);
+            } else {
+              __threadfence_block();
+              coop_push(cand_big, cand_n, fnv_stl::Entry{-di, idi}, lane, ph, 11);
+              __threadfence_block();
             }
+            coop_push(nbr, nbr_n, fnv_stl::Entry{di, idi}, lane, ph, 12);
+            if (nbr_n + 1 > B) coop_pop(nbr, nbr_n + 1, lane, ph, 13);
             cand_n++;
             if (nbr_n < B) nbr_n++;
-            max_dist = rfl(md);
+            max_dist = rfl(nbr.get(0).key);
           }
         }
         __syncthreads();
+        PH_MARK(6);
         if (err) break;
       }
       if (err) break;
     }
+    PH_MARK(2);
 
     // ---- results (Index.h:393-408): drain, std::sort by distance, truncate to K --------------
     __syncthreads();
@@ -463,9 +658,11 @@ __global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p)
     __syncthreads();
     if (any_tie) {
       // Exact replay of the reference's tail: pop everything (descending), std::sort ascending.
+      for (int m = n; m > 1; m--) coop_pop(nbr, m, lane, ph, 7);  // leaves nbr[] ascending
+      __syncthreads();
+      for (int i = lane; i < n; i += WAVE) res[i] = nbr.p[n - 1 - i];  // pop order = descending
+      __syncthreads();
       if (lane == 0) {
-        for (int m = n; m > 1; m--) fnv_stl::heap_pop(nbr, m);  // leaves nbr[] ascending
-        for (int i = 0; i < n; i++) res[i] = nbr.p[n - 1 - i];  // pop order = descending
         LdsHeap r{res};
         fnv_stl::sort_by_key(r, n);
       }
@@ -488,6 +685,8 @@ __global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p)
       if (p.out_nhops) p.out_nhops[qi] = n_hops;
       if (err) atomicMax(p.status, err);
     }
+    PH_MARK(7);
+    PH_FLUSH;
     if (ovf) {  // give the spill bitmap back zeroed
       __threadfence();
       for (uint32_t i = lane; i < p.bitmap_words; i += WAVE) bitmap[i] = 0u;
@@ -496,6 +695,49 @@ __global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p)
     __syncthreads();
   }
 }
+
+#ifdef FNV_PHASE_TIMING
+// Developer micro-benchmark (profiling builds only): cycles per cooperative heap operation on an
+// LDS heap of `size` entries, `blocks` single-wave workgroups running concurrently.
+__global__ __launch_bounds__(WAVE) void heap_microbench_kernel(int size, int iters, unsigned long long* out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x;
+  LdsHeap h{reinterpret_cast<unsigned long long*>(smem + 8)};
+  PhaseTimer ph;
+  ph.start();
+  uint32_t rng = 12345u + blockIdx.x;
+  int n = 0;
+  for (int i = 0; i < size; i++) {
+    rng = rng * 1664525u + 1013904223u;
+    coop_push(h, n, fnv_stl::Entry{(float)(rng >> 8), (uint32_t)i}, lane, ph, 15);
+    n++;
+  }
+  __syncthreads();
+  unsigned long long t0 = clock64();
+  for (int it = 0; it < iters; it++) {
+    rng = rng * 1664525u + 1013904223u;
+    coop_push(h, n, fnv_stl::Entry{(float)(rng >> 8), (uint32_t)it}, lane, ph, 15);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  unsigned long long t1 = clock64();
+  for (int it = 0; it < iters; it++) {
+    coop_pop(h, n + 1, lane, ph, 12);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  unsigned long long t2 = clock64();
+  // plain dependent LDS round trips for reference
+  int idx = lane;
+  for (int it = 0; it < iters; it++) idx = (int)(h.p[idx & 63] & 63);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  unsigned long long t3 = clock64();
+  if (lane == 0 && blockIdx.x == 0) {
+    out[0] = (t1 - t0) / iters;
+    out[1] = (t2 - t1) / iters;
+    out[2] = (t3 - t2) / iters;
+    out[3] = (unsigned long long)idx;
+  }
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // U1: AoS -> SoA re-layout of a staged block of nodes.  One thread per (node, 4-byte word) when
@@ -610,10 +852,11 @@ struct fnv_index_s {
   int32_t* d_labels = nullptr;
   int num_cus = 0;
   // options
-  int64_t visited_factor = 32, visited_slots = 0, cand_factor = 3, cand_slots = 0, spill_entries = 16384,
+  int64_t visited_factor = 32, visited_slots = 0, cand_factor = 2, cand_slots = 0, spill_entries = 16384,
           blocks_per_cu = 0;
   // workspace (grown on demand)
   uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status
+  unsigned long long* d_phase = nullptr;  // profiling builds only
   uint32_t* d_bitmap = nullptr;
   size_t bitmap_bytes = 0;
   unsigned long long* d_spill = nullptr;
@@ -642,6 +885,10 @@ int index_common_init(fnv_index_s* ix) {
   HIP_TRY(hipEventCreate(&ix->ev1));
   HIP_TRY(hipMalloc(&ix->d_dispenser, 2 * sizeof(uint32_t)));
   HIP_TRY(hipMemset(ix->d_dispenser, 0, 2 * sizeof(uint32_t)));
+#ifdef FNV_PHASE_TIMING
+  HIP_TRY(hipMalloc(&ix->d_phase, NPHASE * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(ix->d_phase, 0, NPHASE * sizeof(unsigned long long)));
+#endif
   return FNV_OK;
 }
 
@@ -791,7 +1038,7 @@ int fnv_index_free(fnv_index_t ix) {
   if (!ix) return FNV_OK;
   (void)hipSetDevice(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_bitmap, ix->d_spill, ix->d_q, ix->d_out};
+  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_bitmap, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (ix->ev0) (void)hipEventDestroy(ix->ev0);
@@ -872,7 +1119,7 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
   p.vis_shift = 32;
   for (uint32_t s = p.vis_slots; s > 1; s >>= 1) p.vis_shift--;
   p.vis_limit = p.vis_slots / 4 * 3;
-  p.cand_slots = ix->cand_slots ? (uint32_t)ix->cand_slots : (uint32_t)(ix->cand_factor * p.B);
+  p.cand_slots = ix->cand_slots ? (uint32_t)ix->cand_slots : (uint32_t)(ix->cand_factor * p.B + 256);
   p.cand_slots = std::max<uint32_t>(p.cand_slots, (uint32_t)p.B + 1);  // also hosts the final result list
   p.spill_entries = (uint32_t)ix->spill_entries;
   p.bitmap_words = (uint32_t)((ix->n_nodes + 31) / 32);
@@ -881,10 +1128,10 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
   uint32_t off = 0;
   p.off_q = off;
   off = align16(off + p.q_chunks * 16);
-  p.off_nbr = off;
-  off = align16(off + ((uint32_t)p.B + 2) * 8);
-  p.off_cand = off;
-  off = align16(off + p.cand_slots * 8);
+  p.off_nbr = off + 8;  // heap arrays start at 16n + 8: child pairs are 16-byte aligned
+  off = align16(off + 8 + ((uint32_t)p.B + 2) * 8);
+  p.off_cand = off + 8;
+  off = align16(off + 8 + (p.cand_slots + 1) * 8);
   p.off_vis = off;
   off = align16(off + p.vis_slots * 4);
   p.off_stage_ids = off;
@@ -926,6 +1173,7 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
   p.cand_spill = ix->d_spill;
   p.dispenser = ix->d_dispenser;
   p.status = (int32_t*)(ix->d_dispenser + 1);
+  p.phase_cycles = ix->d_phase;
 
   HIP_TRY(hipMemsetAsync(ix->d_dispenser, 0, 2 * sizeof(uint32_t), stream));
   HIP_TRY(hipEventRecord(ix->ev0, stream));
@@ -1012,6 +1260,27 @@ int fnv_last_kernel_ms(fnv_index_t ix, float* ms) {
   HIP_TRY(hipEventElapsedTime(ms, ix->ev0, ix->ev1));
   return FNV_OK;
 }
+
+#ifdef FNV_PHASE_TIMING
+int fnv_debug_heap_microbench(int size, int iters, int blocks, uint64_t out[4]) {
+  unsigned long long* d = nullptr;
+  HIP_TRY(hipMalloc(&d, 4 * sizeof(unsigned long long)));
+  hipLaunchKernelGGL(heap_microbench_kernel, dim3(blocks), dim3(WAVE), (size + 4) * 8 + 64, 0, size, iters, d);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, d, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipFree(d));
+  return FNV_OK;
+}
+// Profiling builds only: cumulative shader cycles per kernel phase (and reset).
+int fnv_debug_phase_cycles(fnv_index_t ix, uint64_t out[16]) {
+  if (!ix || !out) return fail(FNV_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, ix->d_phase, NPHASE * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(ix->d_phase, 0, NPHASE * sizeof(uint64_t)));
+  return FNV_OK;
+}
+#endif
 
 int fnv_last_launch_geometry(fnv_index_t ix, uint64_t geom[6]) {
   if (!ix || !geom) return fail(FNV_ERR_INVALID, "null argument");

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libflatnav_hip.so")
+LIB_PATH = os.environ.get("FLATNAV_HIP_LIB") or os.path.join(HERE, "libflatnav_hip.so")
 
 FNV_OK, FNV_ERR_INVALID, FNV_ERR_RUNTIME, FNV_ERR_NO_DEVICE, FNV_ERR_CAPACITY = 0, 1, 2, 3, 4
 DTYPE_ORD = {"float32": 9, "uint8": 0, "int8": 4}

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Developer tool: per-phase shader-cycle breakdown of beam_search_kernel on the bench workload.
+
+Builds a profiling variant of the library (-DFNV_PHASE_TIMING -> flatnav_amd/libflatnav_hip_prof.so),
+runs the bench-shaped search and prints cycles per phase per query/hop.  Not part of the product."""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PROF_LIB = os.path.join(ROOT, "flatnav_amd", "libflatnav_hip_prof.so")
+PHASES = ["setup", "entry_scan", "pop(other)", "link_row", "visited", "distances", "admission(other)", "finalize",
+          "candpop.choices", "candpop.chase", "candpop.fix", "candpush", "nbrpush", "nbrpop.choices", "nbrpop.chase",
+          "nbrpop.fix"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--nq", type=int, default=10_000)
+    ap.add_argument("--ef", type=int, default=100)
+    ap.add_argument("--build-only", action="store_true")
+    ap.add_argument("--opt", action="append", default=[])
+    args = ap.parse_args()
+    from flatnav_amd import build as hb
+
+    if not os.path.exists(PROF_LIB) or args.build_only:
+        hb.build(force=True, defines=["FNV_PHASE_TIMING"], out=PROF_LIB)
+    if args.build_only:
+        return
+    os.environ["FLATNAV_HIP_LIB"] = PROF_LIB
+    import numpy as np
+
+    import flatnav_amd as flatnav
+    from flatnav_amd import datasets as ds
+    from flatnav_amd import hip
+
+    X, Q = ds.sift_like(args.n, args.nq)
+    index = flatnav.index.create("l2", 128, args.n, 32)
+    index.set_num_threads(min(192, os.cpu_count()))
+    t0 = time.time()
+    index.add(X, 100)
+    print("build %.1fs" % (time.time() - t0), flush=True)
+    dev = hip.DeviceIndex.upload(np.asarray(index._raw_blob()), index._node_size_bytes, index._data_size_bytes, 32,
+                                 args.n, "float32", "l2", 128)
+    for o in args.opt:
+        k, v = o.split("=")
+        dev.set_option(k, int(v))
+    L = hip.lib()
+    L.fnv_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    dev.search(Q, 10, args.ef)
+    buf = (C.c_uint64 * 16)()
+    L.fnv_debug_phase_cycles(dev._h, buf)  # reset after warm-up
+    _, _, st = dev.search(Q, 10, args.ef, stats=True)
+    ms = dev.last_kernel_ms()
+    L.fnv_debug_phase_cycles(dev._h, buf)
+    cyc = np.array(list(buf), dtype=np.float64)
+    hops = st["n_hops"].sum()
+    print("kernel %.3f ms, %.0f QPS (kernel only, with timing overhead), geometry %s" % (
+        ms, args.nq / ms * 1e3, dev.launch_geometry()))
+    print("%-18s %14s %12s %10s" % ("phase", "cycles/query", "cycles/hop", "share"))
+    for name, c in zip(PHASES, cyc):
+        print("%-18s %14.0f %12.1f %9.1f%%" % (name, c / args.nq, c / hops, 100 * c / cyc.sum()))
+    print("total cycles/query %.0f; hops/query %.1f; dist evals/query %.1f" % (
+        cyc.sum() / args.nq, hops / args.nq, st["n_dist"].mean()))
+
+
+if __name__ == "__main__":
+    main()
