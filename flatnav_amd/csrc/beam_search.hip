@@ -62,6 +62,9 @@ struct SearchParams {
   int K, B;
   uint32_t n_scan, scan_step;
   uint32_t vis_slots, vis_shift, vis_limit;
+  uint32_t vis_tag16;      // 1: 16-bit-tag bucketed table (below), 0: 32-bit open addressing
+  uint32_t vis_bytes;      // LDS bytes of the table
+  uint32_t vis_nmask, vis_rshift, vis_rmask;  // tag16: 2^nbits-1, nbits-log2(buckets), 2^rshift-1
   uint32_t cand_slots, spill_entries, bitmap_words;
   uint32_t off_q, off_nbr, off_cand, off_vis, off_stage_ids, off_stage_d;
 };
@@ -211,7 +214,8 @@ __device__ __forceinline__ void coop_pop(H& h, int n, int lane, PhaseTimer& ph, 
   const uint32_t two1 = (uint32_t)two;  // nodes with 1-based number <= two have two children
   if (two <= WAVE - 1) {
     // <= 63 two-child nodes (heaps of <= 128 entries): one scalar mask, indexed by 1-based number
-    const unsigned long long rw = __ballot(lane >= 1 && lane <= two && !h.leftChildWins(lane - 1));
+    const bool lw = h.leftChildWins(min(max(lane - 1, 0), max(two - 1, 0)));  // always a legal pair
+    const unsigned long long rw = __ballot(lane >= 1 && lane <= two && !lw);
     ph.mark(phbase);
     while (m <= two1) {
       m = (m << 1) | (uint32_t)((rw >> m) & 1ull);
@@ -219,10 +223,11 @@ __device__ __forceinline__ void coop_pop(H& h, int n, int lane, PhaseTimer& ph, 
     }
   } else if (two <= 4 * WAVE) {
     // <= 256 two-child nodes (heaps of <= 514 entries): four scalar masks, indexed by 0-based number
-    unsigned long long r0 = __ballot(lane < two && !h.leftChildWins(lane)), r1 = 0, r2 = 0, r3 = 0;
-    r1 = __ballot(WAVE + lane < two && !h.leftChildWins(WAVE + lane));
-    if (two > 2 * WAVE) r2 = __ballot(2 * WAVE + lane < two && !h.leftChildWins(2 * WAVE + lane));
-    if (two > 3 * WAVE) r3 = __ballot(3 * WAVE + lane < two && !h.leftChildWins(3 * WAVE + lane));
+    // four independent 16-byte reads per lane, issued together (indices clamped to a legal pair)
+    const bool w0 = h.leftChildWins(min(lane, two - 1)), w1 = h.leftChildWins(min(WAVE + lane, two - 1));
+    const bool w2 = h.leftChildWins(min(2 * WAVE + lane, two - 1)), w3 = h.leftChildWins(min(3 * WAVE + lane, two - 1));
+    const unsigned long long r0 = __ballot(lane < two && !w0), r1 = __ballot(WAVE + lane < two && !w1);
+    const unsigned long long r2 = __ballot(2 * WAVE + lane < two && !w2), r3 = __ballot(3 * WAVE + lane < two && !w3);
     ph.mark(phbase);
     while (m <= two1) {
       const uint32_t i0 = m - 1, w = i0 >> 6;
@@ -460,6 +465,47 @@ __device__ __forceinline__ bool visited_lookup_lds(const uint32_t* tab, uint32_t
   }
 }
 
+// Exact visited set in 16 bits per element (used whenever the id width allows it).
+// ids < 2^nbits.  Two multiplicative hashes h_k(id) = (id * A_k) mod 2^nbits, A_k odd, are bijections
+// on nbits-bit integers, so (bucket = top bits of h_k, rem = remaining low bits, k) identifies the
+// id uniquely: the table stores only tag = ((rem << 1) | k) + 1 (0 = empty) -- no false positives.
+// A bucket is four 16-bit tags (8 bytes); an id may sit in either of its two buckets (inserted into
+// the emptier one).  If both buckets are full the id is recorded in the slot's HBM bitmap instead;
+// buckets never lose entries, so "both full -> ask the bitmap" stays consistent for the whole query.
+__device__ __forceinline__ bool has_tag(uint32_t w, uint32_t tag) {
+  return (w & 0xFFFFu) == tag || (w >> 16) == tag;
+}
+__device__ __forceinline__ int zero_halves(uint32_t w) { return ((w & 0xFFFFu) == 0u) + ((w >> 16) == 0u); }
+
+__device__ __forceinline__ bool visited_insert_tag16(uint32_t* tab, const SearchParams& p, uint32_t id,
+                                                     uint32_t* bitmap, bool& used_bitmap) {
+  const uint32_t h1 = (id * 0x9E3779B1u) & p.vis_nmask;
+  const uint32_t h2 = (id * 0x85EBCA6Bu) & p.vis_nmask;
+  const uint32_t b1 = h1 >> p.vis_rshift, b2 = h2 >> p.vis_rshift;
+  const uint32_t t1 = ((h1 & p.vis_rmask) << 1) + 1u, t2 = ((h2 & p.vis_rmask) << 1) + 2u;
+  while (true) {
+    const uint2 B1 = *reinterpret_cast<const uint2*>(tab + 2 * b1);
+    const uint2 B2 = *reinterpret_cast<const uint2*>(tab + 2 * b2);
+    if (has_tag(B1.x, t1) || has_tag(B1.y, t1) || has_tag(B2.x, t2) || has_tag(B2.y, t2)) return false;
+    const int e1 = zero_halves(B1.x) + zero_halves(B1.y), e2 = zero_halves(B2.x) + zero_halves(B2.y);
+    if (e1 == 0 && e2 == 0) {
+      const uint32_t bit = 1u << (id & 31);
+      const uint32_t old = atomicOr(&bitmap[id >> 5], bit);
+      used_bitmap = true;
+      return !(old & bit);
+    }
+    const bool first = e1 >= e2;
+    const uint2 B = first ? B1 : B2;
+    const uint32_t tag = first ? t1 : t2;
+    uint32_t* base = tab + 2 * (first ? b1 : b2);
+    const bool in_x = zero_halves(B.x) > 0;
+    const uint32_t oldw = in_x ? B.x : B.y;
+    const uint32_t neww = oldw | ((oldw & 0xFFFFu) == 0u ? tag : tag << 16);
+    if (atomicCAS(base + (in_x ? 0 : 1), oldw, neww) == oldw) return true;
+    // lost a race for that word: look again
+  }
+}
+
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float rfl(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
@@ -498,7 +544,8 @@ __global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p)
       const int padded = (int)(p.q_chunks * 16u / sizeof(T));
       for (int i = lane; i < padded; i += WAVE) qdst[i] = i < (int)p.dim ? qsrc[i] : T(0);
       uint4* v4 = reinterpret_cast<uint4*>(vis);
-      for (uint32_t i = lane; i < p.vis_slots / 4; i += WAVE) v4[i] = make_uint4(EMPTY_ID, EMPTY_ID, EMPTY_ID, EMPTY_ID);
+      const uint32_t fill = p.vis_tag16 ? 0u : EMPTY_ID;
+      for (uint32_t i = lane; i < p.vis_bytes / 16; i += WAVE) v4[i] = make_uint4(fill, fill, fill, fill);
     }
     __syncthreads();
     PH_MARK(0);
@@ -539,10 +586,14 @@ __global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p)
     if (lane == 0) {
       cand.set(0, fnv_stl::Entry{-best_d, entry});
       nbr.set(0, fnv_stl::Entry{best_d, entry});
-      visited_insert_lds(vis, vis_mask, p.vis_shift, entry);
     }
     uint32_t vis_count = 1;
-    bool ovf = false;
+    bool ovf = false;       // 32-bit table: switched to the bitmap; tag16: some id went to the bitmap
+    if (lane == 0) {
+      if (p.vis_tag16) visited_insert_tag16(vis, p, entry, bitmap, ovf);
+      else visited_insert_lds(vis, vis_mask, p.vis_shift, entry);
+    }
+    ovf = __ballot(ovf) != 0ull;
     int err = ST_OK;
     uint32_t n_dist = 0, n_hops = 0;
     __syncthreads();
@@ -565,14 +616,16 @@ __global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p)
       PH_MARK(2);
 
       for (int m0 = 0; m0 < M; m0 += WAVE) {
-        if (!ovf && vis_count + WAVE > p.vis_limit) ovf = true;
+        if (!p.vis_tag16 && !ovf && vis_count + WAVE > p.vis_limit) ovf = true;
         const bool act = m0 + lane < M;
         uint32_t id = EMPTY_ID;
         if (act) id = p.links[(uint64_t)(uint32_t)node * p.M + m0 + lane];
         PH_MARK(3);
         bool isnew = false;
         if (act) {
-          if (!ovf) {
+          if (p.vis_tag16) {
+            isnew = visited_insert_tag16(vis, p, id, bitmap, ovf);
+          } else if (!ovf) {
             isnew = visited_insert_lds(vis, vis_mask, p.vis_shift, id);
           } else if (!visited_lookup_lds(vis, vis_mask, p.vis_shift, id)) {
             uint32_t bit = 1u << (id & 31);
@@ -580,6 +633,7 @@ __global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p)
             isnew = !(old & bit);
           }
         }
+        ovf = __ballot(ovf) != 0ull;  // wave-uniform
         const unsigned long long newmask = __ballot(isnew);
         const int n = __popcll(newmask);
         if (isnew) stage_ids[__popcll(newmask & ((1ull << lane) - 1ull))] = id;  // keeps link order
@@ -853,7 +907,7 @@ struct fnv_index_s {
   int num_cus = 0;
   // options
   int64_t visited_factor = 32, visited_slots = 0, cand_factor = 2, cand_slots = 0, spill_entries = 16384,
-          blocks_per_cu = 0;
+          blocks_per_cu = 0, visited_wide = 0;
   // workspace (grown on demand)
   uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status
   unsigned long long* d_phase = nullptr;  // profiling builds only
@@ -1061,6 +1115,7 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   else if (n == "cand_slots") ix->cand_slots = value;
   else if (n == "spill_entries") ix->spill_entries = std::max<int64_t>(1, value);
   else if (n == "blocks_per_cu") ix->blocks_per_cu = value;
+  else if (n == "visited_wide") ix->visited_wide = value;
   else return fail(FNV_ERR_INVALID, "unknown option: " + n);
   return FNV_OK;
 }
@@ -1119,6 +1174,19 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
   p.vis_shift = 32;
   for (uint32_t s = p.vis_slots; s > 1; s >>= 1) p.vis_shift--;
   p.vis_limit = p.vis_slots / 4 * 3;
+  {
+    // 16-bit tags need (id bits) - log2(buckets) <= 14; buckets = slots / 4
+    uint32_t nbits = 1;
+    while (nbits < 32 && (1ull << nbits) < ix->n_nodes) nbits++;
+    uint32_t bbits = 0;
+    for (uint32_t b = p.vis_slots / 4; b > 1; b >>= 1) bbits++;
+    const bool can16 = p.vis_slots >= 256 && bbits <= nbits && nbits - bbits <= 14 && nbits < 32;
+    p.vis_tag16 = (can16 && !ix->visited_wide) ? 1u : 0u;
+    p.vis_nmask = (uint32_t)((1ull << nbits) - 1ull);
+    p.vis_rshift = nbits - std::min(bbits, nbits);
+    p.vis_rmask = (1u << p.vis_rshift) - 1u;
+    p.vis_bytes = p.vis_tag16 ? p.vis_slots * 2 : p.vis_slots * 4;
+  }
   p.cand_slots = ix->cand_slots ? (uint32_t)ix->cand_slots : (uint32_t)(ix->cand_factor * p.B + 256);
   p.cand_slots = std::max<uint32_t>(p.cand_slots, (uint32_t)p.B + 1);  // also hosts the final result list
   p.spill_entries = (uint32_t)ix->spill_entries;
@@ -1133,7 +1201,7 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
   p.off_cand = off + 8;
   off = align16(off + 8 + (p.cand_slots + 1) * 8);
   p.off_vis = off;
-  off = align16(off + p.vis_slots * 4);
+  off = align16(off + p.vis_bytes);
   p.off_stage_ids = off;
   off = align16(off + WAVE * 4);
   p.off_stage_d = off;

@@ -99,7 +99,9 @@ int fnv_index_free(fnv_index_t index);
  *   "cand_factor"     LDS candidate-heap capacity = cand_factor * beam width + 256 (default 2)
  *   "cand_slots"      force the LDS candidate-heap capacity (0 = from factor)
  *   "spill_entries"   per-slot HBM spill capacity of the candidate heap (default 16384)
- *   "blocks_per_cu"   cap resident query slots per CU (0 = occupancy limit) */
+ *   "blocks_per_cu"   cap resident query slots per CU (0 = occupancy limit)
+ *   "visited_wide"    1 = always use the 32-bit open-addressing visited table (default 0: the 16-bit-tag
+ *                     bucketed table whenever node-id width allows it) */
 int fnv_set_option(fnv_index_t index, const char* name, int64_t value);
 
 /* Batched search, host buffers.  queries: [nq][dim] elements of the index data type, C-contiguous.

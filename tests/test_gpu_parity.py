@@ -124,9 +124,13 @@ def test_spill_paths_stay_exact(oracle_mod, hipmod):
     ix = _build(oracle_mod, "l2", "float32", X, 32)
     o = ix.search(Q, 10, 100, stats=True)
     dev = _upload(hipmod, ix)
-    dev.set_option("visited_slots", 256)
+    dev.set_option("visited_slots", 256)  # 16-bit-tag table, 64 buckets: most ids end up in the bitmap
     _assert_exact(o, dev.search(Q, 10, 100, stats=True))
-    dev.set_option("visited_slots", 0)
+    dev.set_option("visited_wide", 1)     # 32-bit open-addressing table, also far too small
+    _assert_exact(o, dev.search(Q, 10, 100, stats=True))
+    dev.set_option("visited_slots", 0)    # ... and at its default size
+    _assert_exact(o, dev.search(Q, 10, 100, stats=True))
+    dev.set_option("visited_wide", 0)
     dev.set_option("cand_slots", 8)  # kernel raises it to B+1, far below the ~2.6*B admissions
     _assert_exact(o, dev.search(Q, 10, 100, stats=True))
     # a second search on the same slots must see clean spill bitmaps
