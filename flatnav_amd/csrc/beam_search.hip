@@ -39,8 +39,12 @@ namespace {
 constexpr uint32_t EMPTY_ID = 0xFFFFFFFFu;
 constexpr int WAVE = 64;
 constexpr int PU = 4;  // vector "passes" whose loads are issued back to back before any use
+#ifndef FNV_MIN_WAVES_PER_SIMD
+#define FNV_MIN_WAVES_PER_SIMD 3  // __launch_bounds__ 2nd argument: register budget 512/3 per lane
+#endif
 
 enum : int { ST_OK = 0, ST_CAND_OVERFLOW = 1 };
+constexpr uint32_t OVF_LIST = 30;  // ids remembered for a cheap clean-up of the HBM visited bitmap
 
 struct SearchParams {
   const uint8_t* vectors;   // [n_nodes][row_bytes]
@@ -64,7 +68,9 @@ struct SearchParams {
   uint32_t vis_slots, vis_shift, vis_limit;
   uint32_t vis_tag16;      // 1: 16-bit-tag bucketed table (below), 0: 32-bit open addressing
   uint32_t vis_bytes;      // LDS bytes of the table
-  uint32_t vis_nmask, vis_rshift, vis_rmask;  // tag16: 2^nbits-1, nbits-log2(buckets), 2^rshift-1
+  uint32_t vis_nmask, vis_rshift, vis_rmask;  // tag16: 2^nbits-1, t = nbits-k, 2^t-1
+  uint32_t vis_mult;       // tag16: buckets = vis_mult * 2^k with vis_mult in {1, 3}
+  uint32_t off_ovf;        // LDS: [0] count, [1..OVF_LIST] ids that went to the HBM bitmap
   uint32_t cand_slots, spill_entries, bitmap_words;
   uint32_t off_q, off_nbr, off_cand, off_vis, off_stage_ids, off_stage_d;
 };
@@ -477,12 +483,22 @@ __device__ __forceinline__ bool has_tag(uint32_t w, uint32_t tag) {
 }
 __device__ __forceinline__ int zero_halves(uint32_t w) { return ((w & 0xFFFFu) == 0u) + ((w >> 16) == 0u); }
 
+// Bucket geometry: buckets = mult * 2^k (mult 1 or 3, so tables of 2^j or 3*2^j slots exist), t = nbits - k.
+// x = h * mult; bucket = x >> t; the low t bits of x, divided by mult, number the ids inside the bucket.
+__device__ __forceinline__ void tag16_slot(const SearchParams& p, uint32_t h, uint32_t which, uint32_t& bucket,
+                                           uint32_t& tag) {
+  const uint32_t x = h * p.vis_mult;
+  bucket = x >> p.vis_rshift;
+  uint32_t rem = x & p.vis_rmask;
+  if (p.vis_mult == 3) rem = (rem * 43691u) >> 17;  // rem / 3, exact below 2^16
+  tag = (rem << 1) + 1u + which;
+}
+
 __device__ __forceinline__ bool visited_insert_tag16(uint32_t* tab, const SearchParams& p, uint32_t id,
-                                                     uint32_t* bitmap, bool& used_bitmap) {
-  const uint32_t h1 = (id * 0x9E3779B1u) & p.vis_nmask;
-  const uint32_t h2 = (id * 0x85EBCA6Bu) & p.vis_nmask;
-  const uint32_t b1 = h1 >> p.vis_rshift, b2 = h2 >> p.vis_rshift;
-  const uint32_t t1 = ((h1 & p.vis_rmask) << 1) + 1u, t2 = ((h2 & p.vis_rmask) << 1) + 2u;
+                                                     uint32_t* bitmap, uint32_t* ovf_list, bool& used_bitmap) {
+  uint32_t b1, b2, t1, t2;
+  tag16_slot(p, (id * 0x9E3779B1u) & p.vis_nmask, 0u, b1, t1);
+  tag16_slot(p, (id * 0x85EBCA6Bu) & p.vis_nmask, 1u, b2, t2);
   while (true) {
     const uint2 B1 = *reinterpret_cast<const uint2*>(tab + 2 * b1);
     const uint2 B2 = *reinterpret_cast<const uint2*>(tab + 2 * b2);
@@ -492,7 +508,12 @@ __device__ __forceinline__ bool visited_insert_tag16(uint32_t* tab, const Search
       const uint32_t bit = 1u << (id & 31);
       const uint32_t old = atomicOr(&bitmap[id >> 5], bit);
       used_bitmap = true;
-      return !(old & bit);
+      if (!(old & bit)) {
+        const uint32_t pos = atomicAdd(&ovf_list[0], 1u);
+        if (pos < OVF_LIST) ovf_list[1 + pos] = id;
+        return true;
+      }
+      return false;
     }
     const bool first = e1 >= e2;
     const uint2 B = first ? B1 : B2;
@@ -513,7 +534,7 @@ __device__ __forceinline__ float rfl(float v) { return __int_as_float(__builtin_
 // The search kernel.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int METRIC, int G, int CU>
-__global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p) {
+__global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kernel(const SearchParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
   uint4* qlds = reinterpret_cast<uint4*>(smem + p.off_q);
@@ -525,6 +546,7 @@ __global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p)
   uint32_t* stage_ids = reinterpret_cast<uint32_t*>(smem + p.off_stage_ids);
   float* stage_d = reinterpret_cast<float*>(smem + p.off_stage_d);
   uint32_t* bitmap = p.ovf_bitmap + (uint64_t)blockIdx.x * p.bitmap_words;
+  uint32_t* ovf_list = reinterpret_cast<uint32_t*>(smem + p.off_ovf);
   const uint32_t vis_mask = p.vis_slots - 1;
   const int B = p.B;
   const int K = p.K;
@@ -546,6 +568,7 @@ __global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p)
       uint4* v4 = reinterpret_cast<uint4*>(vis);
       const uint32_t fill = p.vis_tag16 ? 0u : EMPTY_ID;
       for (uint32_t i = lane; i < p.vis_bytes / 16; i += WAVE) v4[i] = make_uint4(fill, fill, fill, fill);
+      if (lane == 0) ovf_list[0] = 0u;
     }
     __syncthreads();
     PH_MARK(0);
@@ -590,7 +613,7 @@ __global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p)
     uint32_t vis_count = 1;
     bool ovf = false;       // 32-bit table: switched to the bitmap; tag16: some id went to the bitmap
     if (lane == 0) {
-      if (p.vis_tag16) visited_insert_tag16(vis, p, entry, bitmap, ovf);
+      if (p.vis_tag16) visited_insert_tag16(vis, p, entry, bitmap, ovf_list, ovf);
       else visited_insert_lds(vis, vis_mask, p.vis_shift, entry);
     }
     ovf = __ballot(ovf) != 0ull;
@@ -624,7 +647,7 @@ __global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p)
         bool isnew = false;
         if (act) {
           if (p.vis_tag16) {
-            isnew = visited_insert_tag16(vis, p, id, bitmap, ovf);
+            isnew = visited_insert_tag16(vis, p, id, bitmap, ovf_list, ovf);
           } else if (!ovf) {
             isnew = visited_insert_lds(vis, vis_mask, p.vis_shift, id);
           } else if (!visited_lookup_lds(vis, vis_mask, p.vis_shift, id)) {
@@ -743,7 +766,12 @@ __global__ __launch_bounds__(WAVE) void beam_search_kernel(const SearchParams p)
     PH_FLUSH;
     if (ovf) {  // give the spill bitmap back zeroed
       __threadfence();
-      for (uint32_t i = lane; i < p.bitmap_words; i += WAVE) bitmap[i] = 0u;
+      const uint32_t listed = ovf_list[0];
+      if (p.vis_tag16 && listed <= OVF_LIST) {  // few ids: clear just their words
+        if ((uint32_t)lane < listed) bitmap[ovf_list[1 + lane] >> 5] = 0u;
+      } else {
+        for (uint32_t i = lane; i < p.bitmap_words; i += WAVE) bitmap[i] = 0u;
+      }
       __threadfence();
     }
     __syncthreads();
@@ -906,7 +934,7 @@ struct fnv_index_s {
   int32_t* d_labels = nullptr;
   int num_cus = 0;
   // options
-  int64_t visited_factor = 32, visited_slots = 0, cand_factor = 2, cand_slots = 0, spill_entries = 16384,
+  int64_t visited_factor = 22, visited_slots = 0, cand_factor = 2, cand_slots = 0, spill_entries = 16384,
           blocks_per_cu = 0, visited_wide = 0;
   // workspace (grown on demand)
   uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status
@@ -1108,7 +1136,8 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   if (value < 0) return fail(FNV_ERR_INVALID, "option values must be non-negative");
   if (n == "visited_factor") ix->visited_factor = std::max<int64_t>(1, value);
   else if (n == "visited_slots") {
-    if (value && (value & (value - 1))) return fail(FNV_ERR_INVALID, "visited_slots must be a power of two");
+    if (value && (value & (value - 1)) && ((value % 3) || ((value / 3) & (value / 3 - 1))))
+      return fail(FNV_ERR_INVALID, "visited_slots must be 2^j or 3*2^j");
     if (value && value < 256) return fail(FNV_ERR_INVALID, "visited_slots must be at least 256");
     ix->visited_slots = value;
   } else if (n == "cand_factor") ix->cand_factor = std::max<int64_t>(1, value);
@@ -1168,26 +1197,45 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
   const uint32_t per_iter = (uint32_t)(kCfgs[cfg].G * kCfgs[cfg].CU);
   p.q_chunks = (p.nchunks + per_iter - 1) / per_iter * per_iter;
 
-  p.vis_slots = ix->visited_slots ? (uint32_t)ix->visited_slots
-                                  : std::max<uint32_t>(256, pow2_ceil((uint64_t)ix->visited_factor * (uint64_t)p.B));
-  p.vis_slots = std::min<uint32_t>(p.vis_slots, 1u << 15);  // 128 KiB of LDS at most
-  p.vis_shift = 32;
-  for (uint32_t s = p.vis_slots; s > 1; s >>= 1) p.vis_shift--;
-  p.vis_limit = p.vis_slots / 4 * 3;
   {
-    // 16-bit tags need (id bits) - log2(buckets) <= 14; buckets = slots / 4
+    // Visited-table geometry.  Slots = 2^j or 3*2^j.  16-bit tags whenever the per-bucket id range
+    // fits 14 bits: buckets = mult*2^k, t = nbits - k, need t <= 14 (mult 1) or t <= 15 (mult 3).
     uint32_t nbits = 1;
     while (nbits < 32 && (1ull << nbits) < ix->n_nodes) nbits++;
-    uint32_t bbits = 0;
-    for (uint32_t b = p.vis_slots / 4; b > 1; b >>= 1) bbits++;
-    const bool can16 = p.vis_slots >= 256 && bbits <= nbits && nbits - bbits <= 14 && nbits < 32;
-    p.vis_tag16 = (can16 && !ix->visited_wide) ? 1u : 0u;
+    uint64_t want = ix->visited_slots ? (uint64_t)ix->visited_slots
+                                      : (uint64_t)ix->visited_factor * (uint64_t)p.B + 640;
+    want = std::max<uint64_t>(want, 256);
+    uint32_t slots = 256;
+    for (uint32_t base = 256;; base <<= 1) {  // candidates in increasing order: 2^j, 3*2^(j-1), 2^(j+1), ...
+      if (base >= want || base >= (1u << 15)) {
+        slots = base;
+        break;
+      }
+      if ((uint64_t)base / 2 * 3 >= want) {
+        slots = base / 2 * 3;
+        break;
+      }
+    }
+    if (ix->visited_slots) slots = (uint32_t)ix->visited_slots;
+    const uint32_t mult = (slots % 3 == 0) ? 3u : 1u;
+    uint32_t k = 0;
+    for (uint32_t b = slots / 4 / mult; b > 1; b >>= 1) k++;
+    bool can16 = !ix->visited_wide && nbits <= 30 && k <= nbits && (nbits - k) <= (mult == 3 ? 15u : 14u);
+    if (!can16 && mult == 3) {  // the 32-bit table needs a power of two
+      slots = pow2_ceil(slots);
+    }
+    p.vis_slots = slots;
+    p.vis_tag16 = can16 ? 1u : 0u;
+    p.vis_mult = mult;
     p.vis_nmask = (uint32_t)((1ull << nbits) - 1ull);
-    p.vis_rshift = nbits - std::min(bbits, nbits);
-    p.vis_rmask = (1u << p.vis_rshift) - 1u;
-    p.vis_bytes = p.vis_tag16 ? p.vis_slots * 2 : p.vis_slots * 4;
+    p.vis_rshift = can16 ? nbits - k : 0;
+    p.vis_rmask = can16 ? ((1u << p.vis_rshift) - 1u) : 0;
+    p.vis_bytes = can16 ? slots * 2 : slots * 4;
+    p.vis_shift = 32;
+    for (uint32_t sft = p.vis_slots; sft > 1; sft >>= 1) p.vis_shift--;
+    p.vis_limit = p.vis_slots / 4 * 3;
   }
-  p.cand_slots = ix->cand_slots ? (uint32_t)ix->cand_slots : (uint32_t)(ix->cand_factor * p.B + 256);
+  p.cand_slots = ix->cand_slots ? (uint32_t)ix->cand_slots : (uint32_t)(ix->cand_factor * p.B + 192);
   p.cand_slots = std::max<uint32_t>(p.cand_slots, (uint32_t)p.B + 1);  // also hosts the final result list
   p.spill_entries = (uint32_t)ix->spill_entries;
   p.bitmap_words = (uint32_t)((ix->n_nodes + 31) / 32);
@@ -1206,6 +1254,8 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
   off = align16(off + WAVE * 4);
   p.off_stage_d = off;
   off = align16(off + WAVE * 4);
+  p.off_ovf = off;
+  off = align16(off + (OVF_LIST + 2) * 4);
   const uint32_t lds_bytes = off;
   if (lds_bytes > 160u * 1024u)
     return fail(FNV_ERR_INVALID, "ef_search too large for the on-chip beam state (needs " + std::to_string(lds_bytes) +

@@ -1,0 +1,71 @@
+"""C-ABI surface checks that need no GPU: the shared library builds for gfx950, loads, and exports
+exactly the symbols include/flatnav_hip.h declares.  No compute entry point is called here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from flatnav_amd import build
+
+    return build.build()  # hipcc cross-compiles for gfx950 without a GPU
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "flatnav_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fnv_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    from flatnav_amd import hip
+
+    assert _declared_symbols() == sorted(hip.C_ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(libpath):
+    lib = C.CDLL(libpath)
+    for name in _declared_symbols():
+        assert hasattr(lib, name), name
+    lib.fnv_version.restype = C.c_char_p
+    assert b"gfx950" in lib.fnv_version()
+    lib.fnv_last_error.restype = C.c_char_p
+    assert lib.fnv_last_error() is not None
+
+
+def test_library_contains_gfx950_code_object(libpath):
+    blob = open(libpath, "rb").read()
+    assert b"gfx950" in blob and b"beam_search_kernel" in blob
+
+
+def test_argument_validation_needs_no_device(libpath):
+    from flatnav_amd import hip
+
+    L = hip.lib()
+    h = C.c_void_p()
+    # unsupported data type -> runtime error (reference: "Unsupported data type", bindings.cpp:498-499)
+    assert L.fnv_index_alloc(8, 100, 3, 0, 16, 0, C.byref(h)) == hip.FNV_ERR_RUNTIME
+    # empty index / bad metric -> invalid argument
+    assert L.fnv_index_alloc(8, 0, 9, 0, 16, 0, C.byref(h)) == hip.FNV_ERR_INVALID
+    assert L.fnv_index_alloc(8, 100, 9, 7, 16, 0, C.byref(h)) == hip.FNV_ERR_INVALID
+    assert L.fnv_search_batch(None, None, 1, 1, 1, 1, None, None, None, None, None) == hip.FNV_ERR_INVALID
+    assert b"index is null" in L.fnv_last_error()
+
+
+def test_search_without_gpu_fails_loudly():
+    import numpy as np
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; this checks the no-device error path")
+    import flatnav_amd as flatnav
+
+    ix = flatnav.index.create("l2", 8, 64, 4)
+    ix.add(np.random.default_rng(0).random((64, 8), dtype=np.float32), 16)
+    with pytest.raises(RuntimeError):
+        ix.search(np.zeros((2, 8), dtype=np.float32), 3, 10)  # never falls back to a CPU search
