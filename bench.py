@@ -35,11 +35,18 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-class _DevView:
-    """Expose a raw device pointer to torch through the CUDA array interface."""
-
-    def __init__(self, ptr: int, nbytes: int):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+def recorded_traffic(n, nq, ef):
+    """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes); None unless this run is the
+    very workload those passes profiled."""
+    path = os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if (rec.get("n"), rec.get("nq"), rec.get("ef")) != (n, nq, ef):
+        return None
+    return rec.get("hbm_bytes_per_launch_corrected")
 
 
 def main() -> None:
@@ -108,11 +115,10 @@ def main() -> None:
     else:
         dev = hip.DeviceIndex.alloc(M, N, "float32", "l2", DIM, device=local_rank)
     if world > 1:
+        from flatnav_amd import multigpu
+
         t0 = time.time()
-        for ptr, nbytes in dev.device_buffers():
-            t = torch.as_tensor(_DevView(ptr, nbytes), device="cuda:%d" % local_rank)
-            dist.broadcast(t, src=0)  # RCCL over xGMI, once at load
-        torch.cuda.synchronize()
+        multigpu.replicate_index(dev, local_rank, src=0)  # one RCCL broadcast per buffer over xGMI, at load only
         log("[rank %d] index broadcast %.2fs" % (rank, time.time() - t0))
     for o in args.opt:
         k, v = o.split("=")
@@ -206,12 +212,12 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "beam_search_kernel<float, L2, G=8, CU=4>",
+                "kernel": "beam_search_kernel<float, 0, 8, 4>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": recorded_traffic(N, NQ, EF),
                 "algorithmic_bytes_per_launch": bytes_launch,
                 "avg_kernel_ms": avg_kernel_s * 1e3,
             },
