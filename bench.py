@@ -186,6 +186,12 @@ def main() -> None:
         recall = ds.recall_at_k(labels[:nrec], gt.cpu().numpy())
         del xt, xn
         geom = dev.launch_geometry()
+        # informational: the host-buffer entry point (pageable H2D of the queries + kernel + D2H of results)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            dev.search(Q, K, EF)
+        host_qps = 3 * NQ / (time.perf_counter() - t0)
+        log("[rank 0] host-buffer (PCIe-inclusive) path: %.0f queries/s" % host_qps)
         total_q = NQ * world * args.steps
         out = {
             "metric": "qps_at_recall10_ge_0.95",
@@ -209,6 +215,7 @@ def main() -> None:
                 "mean_dist_evals_per_query": float(nd.mean()),
                 "mean_hops_per_query": float(nh.mean()),
                 "launch": geom,
+                "host_buffer_qps_pcie_inclusive": round(host_qps),
             },
             "roofline": {
                 "bound": "hbm",

@@ -17,6 +17,10 @@ import sys as _sys
 
 __version__ = "0.1.0"
 
+from ._runtime import preload_hip_runtime as _preload_hip_runtime
+
+_preload_hip_runtime()  # share torch's bundled HIP runtime when torch is installed (see _runtime.py)
+
 try:
     from . import _core
 except ImportError as _e:  # built in-tree by `python -m flatnav_amd.build_host`

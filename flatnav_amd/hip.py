@@ -41,6 +41,9 @@ def lib() -> C.CDLL:
         raise DeviceUnavailable(
             "flatnav_amd: %s is missing -- build it with `python -m flatnav_amd.build` "
             "(there is no CPU fallback for the search path)" % LIB_PATH)
+    from ._runtime import preload_hip_runtime
+
+    preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     L.fnv_last_error.restype = C.c_char_p
     L.fnv_version.restype = C.c_char_p
