@@ -322,29 +322,35 @@ __device__ __forceinline__ A group_sum(A v) {
 template <typename T, int METRIC>
 struct Dist;
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int METRIC>
 struct Dist<float, METRIC> {
-  typedef float acc_t;
-  static __device__ __forceinline__ float chunk(float acc, const uint4& x, const uint4& y) {
-    const float xs[4] = {__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w)};
-    const float ys[4] = {__uint_as_float(y.x), __uint_as_float(y.y), __uint_as_float(y.z), __uint_as_float(y.w)};
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      if (METRIC == FNV_METRIC_L2) {
-        float t = xs[i] - ys[i];
-        acc = fmaf(t, t, acc);
-      } else {
-        acc = fmaf(xs[i], ys[i], acc);
-      }
+  // two partial sums per lane so subtract and multiply-add issue as packed f32 (v_pk_add_f32 / v_pk_fma_f32)
+  typedef f32x2 acc_t;
+  static __device__ __forceinline__ f32x2 zero() { return f32x2{0.f, 0.f}; }
+  static __device__ __forceinline__ f32x2 chunk(f32x2 acc, const uint4& x, const uint4& y) {
+    const f32x2 x0 = {__uint_as_float(x.x), __uint_as_float(x.y)}, x1 = {__uint_as_float(x.z), __uint_as_float(x.w)};
+    const f32x2 y0 = {__uint_as_float(y.x), __uint_as_float(y.y)}, y1 = {__uint_as_float(y.z), __uint_as_float(y.w)};
+    if (METRIC == FNV_METRIC_L2) {
+      const f32x2 t0 = x0 - y0, t1 = x1 - y1;
+      acc = __builtin_elementwise_fma(t0, t0, acc);
+      acc = __builtin_elementwise_fma(t1, t1, acc);
+    } else {
+      acc = __builtin_elementwise_fma(x0, y0, acc);
+      acc = __builtin_elementwise_fma(x1, y1, acc);
     }
     return acc;
   }
+  static __device__ __forceinline__ float lane_sum(f32x2 a) { return a.x + a.y; }
   static __device__ __forceinline__ float finish(float s) { return METRIC == FNV_METRIC_L2 ? s : 1.0f - s; }
 };
 
 template <typename T, int METRIC>
 struct DistInt {
   typedef int acc_t;
+  static __device__ __forceinline__ int zero() { return 0; }
+  static __device__ __forceinline__ int lane_sum(int a) { return a; }
   static __device__ __forceinline__ int elem(uint32_t w, int k) {
     if (sizeof(T) == 1 && T(-1) < T(0)) return (int)(int8_t)(w >> (8 * k));
     return (int)((w >> (8 * k)) & 0xffu);
@@ -377,68 +383,86 @@ template <int METRIC>
 struct Dist<int8_t, METRIC> : DistInt<int8_t, METRIC> {};
 
 // ---------------------------------------------------------------------------------------------
-// Distances from the query (in LDS, zero padded to q_chunks) to `n` nodes whose ids sit in LDS.
-// Lane layout: g = lane % G walks the 16-byte chunks of a row (chunk g, g+G, ...), v = lane / G
-// picks the vector of the pass; a pass covers 64/G vectors; PU passes are fetched together.
+// Distances from the query (in LDS, zero padded to q_chunks) to one BATCH of up to PU * (64/G) nodes.
+// Lane layout: g = lane % G walks the 16-byte chunks of a row (chunk g, g+G, ...), v = lane / G picks the
+// vector of a pass; pass pu holds batch slot pu*(64/G) + v.  Inputs id[pu] / valid[pu] are per lane (equal
+// within a G-lane group); `npass` (wave-uniform) = number of passes that hold at least one vector.  All
+// PU*CU loads of an inner iteration are issued before the first use.  Results stay in registers: every
+// lane of a group ends with the group's distance in out[pu].
 // ---------------------------------------------------------------------------------------------
-template <typename T, int METRIC, int G, int CU>
-__device__ __forceinline__ void compute_dists(const SearchParams& p, const uint4* qlds, const uint32_t* ids, int n,
-                                              float* outd, int lane) {
+template <typename T, int METRIC, int G, int CU, bool FULL>
+__device__ __forceinline__ void batch_dists(const SearchParams& p, const uint4* qlds, const uint32_t (&id)[PU],
+                                            const bool (&valid)[PU], int npass, float (&out)[PU], int lane) {
   typedef Dist<T, METRIC> D;
   typedef typename D::acc_t acc_t;
-  constexpr int VPW = WAVE / G;
   const int g = lane % G;
-  const int v = lane / G;
   const int nchunks = (int)p.nchunks;
-
-  for (int base = 0; base < n; base += VPW * PU) {
-    acc_t acc[PU];
-    const uint8_t* rowp[PU];
-    bool valid[PU];
+  acc_t acc[PU];
+  const uint8_t* rowp[PU];
 #pragma unroll
-    for (int pu = 0; pu < PU; pu++) {
-      int slot = base + pu * VPW + v;
-      valid[pu] = slot < n;
-      uint32_t id = valid[pu] ? ids[slot] : 0u;
-      rowp[pu] = p.vectors + (uint64_t)id * p.row_bytes;
-      acc[pu] = 0;
-    }
+  for (int pu = 0; pu < PU; pu++) {
+    rowp[pu] = p.vectors + (uint64_t)(valid[pu] ? id[pu] : 0u) * p.row_bytes;
+    acc[pu] = D::zero();
+  }
+  if (FULL) {
+    // rows are a whole number of G*CU-chunk spans (e.g. d=128 f32: 32 chunks = 8 lanes x 4): no clamping, no
+    // tail select; one address per pass, the CU loads use immediate offsets
+#pragma unroll
+    for (int pu = 0; pu < PU; pu++) rowp[pu] += g * 16;
     for (int c0 = 0; c0 < nchunks; c0 += G * CU) {
       uint4 y[PU][CU];
 #pragma unroll
       for (int pu = 0; pu < PU; pu++) {
-        if (base + pu * VPW < n) {  // wave-uniform: skip passes that hold no vector at all
+        if (pu < npass) {  // wave-uniform: skip passes that hold no vector at all
 #pragma unroll
-          for (int cu = 0; cu < CU; cu++) {
-            int c = c0 + cu * G + g;
-            int cc = c < nchunks ? c : nchunks - 1;  // clamp: always a legal address
-            y[pu][cu] = valid[pu] ? *reinterpret_cast<const uint4*>(rowp[pu] + (uint32_t)cc * 16u)
+          for (int cu = 0; cu < CU; cu++)
+            y[pu][cu] = valid[pu] ? *reinterpret_cast<const uint4*>(rowp[pu] + (c0 + cu * G) * 16)
                                   : make_uint4(0, 0, 0, 0);
-          }
         }
       }
 #pragma unroll
       for (int cu = 0; cu < CU; cu++) {
-        int c = c0 + cu * G + g;
-        uint4 x = qlds[c];  // zero beyond the row (q_chunks covers the last c0 block)
-        bool in_row = c < nchunks;
+        const uint4 x = qlds[c0 + cu * G + g];
 #pragma unroll
-        for (int pu = 0; pu < PU; pu++) {
-          if (base + pu * VPW < n) {
-            uint4 yy = y[pu][cu];
-            if (!in_row) yy = x;  // x is zero there: (0-0)^2 = 0 and 0*0 = 0
-            acc[pu] = D::chunk(acc[pu], x, yy);
-          }
+        for (int pu = 0; pu < PU; pu++)
+          if (pu < npass) acc[pu] = D::chunk(acc[pu], x, y[pu][cu]);
+      }
+    }
+  } else {
+  for (int c0 = 0; c0 < nchunks; c0 += G * CU) {
+    uint4 y[PU][CU];
+#pragma unroll
+    for (int pu = 0; pu < PU; pu++) {
+      if (pu < npass) {  // wave-uniform: skip passes that hold no vector at all
+#pragma unroll
+        for (int cu = 0; cu < CU; cu++) {
+          const int c = c0 + cu * G + g;
+          const int cc = c < nchunks ? c : nchunks - 1;  // clamp: always a legal address
+          y[pu][cu] = valid[pu] ? *reinterpret_cast<const uint4*>(rowp[pu] + (uint32_t)cc * 16u)
+                                : make_uint4(0, 0, 0, 0);
         }
       }
     }
 #pragma unroll
-    for (int pu = 0; pu < PU; pu++) {
-      if (base + pu * VPW < n) {
-        acc_t s = group_sum<G>(acc[pu]);
-        if (g == 0 && valid[pu]) outd[base + pu * VPW + v] = D::finish(s);
+    for (int cu = 0; cu < CU; cu++) {
+      const int c = c0 + cu * G + g;
+      const uint4 x = qlds[c];  // zero beyond the row (q_chunks covers the last c0 block)
+      const bool in_row = c < nchunks;
+#pragma unroll
+      for (int pu = 0; pu < PU; pu++) {
+        if (pu < npass) {
+          uint4 yy = y[pu][cu];
+          if (!in_row) yy = x;  // x is zero there: (0-0)^2 = 0 and 0*0 = 0
+          acc[pu] = D::chunk(acc[pu], x, yy);
+        }
       }
     }
+  }
+  }
+#pragma unroll
+  for (int pu = 0; pu < PU; pu++) {
+    out[pu] = 0.f;
+    if (pu < npass) out[pu] = D::finish(group_sum<G>(D::lane_sum(acc[pu])));
   }
 }
 
@@ -533,7 +557,7 @@ __device__ __forceinline__ float rfl(float v) { return __int_as_float(__builtin_
 // ---------------------------------------------------------------------------------------------
 // The search kernel.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int METRIC, int G, int CU>
+template <typename T, int METRIC, int G, int CU, bool FULL>
 __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kernel(const SearchParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
@@ -544,7 +568,6 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
                     p.cand_spill + (uint64_t)blockIdx.x * p.spill_entries, (int)p.cand_slots};
   uint32_t* vis = reinterpret_cast<uint32_t*>(smem + p.off_vis);
   uint32_t* stage_ids = reinterpret_cast<uint32_t*>(smem + p.off_stage_ids);
-  float* stage_d = reinterpret_cast<float*>(smem + p.off_stage_d);
   uint32_t* bitmap = p.ovf_bitmap + (uint64_t)blockIdx.x * p.bitmap_words;
   uint32_t* ovf_list = reinterpret_cast<uint32_t*>(smem + p.off_ovf);
   const uint32_t vis_mask = p.vis_slots - 1;
@@ -576,20 +599,29 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
     // ---- entry-point selection (Index.h:845-870): argmin over nodes 0, s, 2s, ... -----------
     float best_d = std::numeric_limits<float>::max();
     uint32_t best_j = 0;
-    for (uint32_t j0 = 0; j0 < p.n_scan; j0 += WAVE) {
-      int cnt = (int)min((uint32_t)WAVE, p.n_scan - j0);
-      if (lane < cnt) stage_ids[lane] = (j0 + lane) * p.scan_step;
-      __syncthreads();
-      compute_dists<T, METRIC, G, CU>(p, qlds, stage_ids, cnt, stage_d, lane);
-      __syncthreads();
-      if (lane < cnt) {
-        float d = stage_d[lane];
-        if (d < best_d) {  // strict '<': first minimum wins (Index.h:864)
-          best_d = d;
-          best_j = j0 + lane;
+    {
+      constexpr int VPW = WAVE / G;
+      const int v = lane / G;
+      for (uint32_t j0 = 0; j0 < p.n_scan; j0 += VPW * PU) {
+        uint32_t sid[PU];
+        bool sval[PU];
+        float sd[PU];
+#pragma unroll
+        for (int pu = 0; pu < PU; pu++) {
+          const uint32_t j = j0 + pu * VPW + v;
+          sval[pu] = j < p.n_scan;
+          sid[pu] = j * p.scan_step;
+        }
+        const int npass = (int)min((uint32_t)PU, (p.n_scan - j0 + VPW - 1) / VPW);
+        batch_dists<T, METRIC, G, CU, FULL>(p, qlds, sid, sval, npass, sd, lane);
+#pragma unroll
+        for (int pu = 0; pu < PU; pu++) {
+          if (sval[pu] && sd[pu] < best_d) {  // strict '<': first minimum wins (Index.h:864)
+            best_d = sd[pu];
+            best_j = j0 + pu * VPW + v;
+          }
         }
       }
-      __syncthreads();
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -627,6 +659,9 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
       const float ctop_d = -rfl(ctop.key);
       if (ctop_d > max_dist && nbr_n >= B) break;  // Index.h:630
       const int node = rfl((int)ctop.val);
+      // issue the link-row load now; the cooperative pop below hides most of its HBM latency
+      uint32_t row_id = EMPTY_ID;
+      if (lane < M) row_id = p.links[(uint64_t)(uint32_t)node * p.M + lane];
       if (cand_n <= (int)p.cand_slots) {
         coop_pop(cand, cand_n, lane, ph, 8);
       } else {  // part of the heap lives in the HBM spill area
@@ -641,8 +676,8 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
       for (int m0 = 0; m0 < M; m0 += WAVE) {
         if (!p.vis_tag16 && !ovf && vis_count + WAVE > p.vis_limit) ovf = true;
         const bool act = m0 + lane < M;
-        uint32_t id = EMPTY_ID;
-        if (act) id = p.links[(uint64_t)(uint32_t)node * p.M + m0 + lane];
+        uint32_t id = row_id;
+        if (m0 > 0) id = act ? p.links[(uint64_t)(uint32_t)node * p.M + m0 + lane] : EMPTY_ID;
         PH_MARK(3);
         bool isnew = false;
         if (act) {
@@ -661,50 +696,66 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
         const int n = __popcll(newmask);
         if (isnew) stage_ids[__popcll(newmask & ((1ull << lane) - 1ull))] = id;  // keeps link order
         vis_count += n;
-        __syncthreads();
+        wave_sync();
         PH_MARK(4);
         if (n == 0) continue;
-        compute_dists<T, METRIC, G, CU>(p, qlds, stage_ids, n, stage_d, lane);
-        __syncthreads();
         n_dist += n;
-        PH_MARK(5);
 
-        float d = 0.f;
-        uint32_t cid = 0;
-        if (lane < n) {
-          d = stage_d[lane];
-          cid = stage_ids[lane];
-        }
-        // Superset filter: max_dist never grows once the beam is full, so anything that fails
-        // here would also fail the sequential test below.
-        unsigned long long pm = __ballot(lane < n && (nbr_n < B || d < max_dist));
-        while (pm) {
-          const int i = __ffsll((long long)pm) - 1;
-          pm &= pm - 1;
-          const float di = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), i));
-          const uint32_t idi = (uint32_t)__builtin_amdgcn_readlane((int)cid, i);
-          if (nbr_n < B || di < max_dist) {  // Index.h:693
-            if (cand_n >= (int)(p.cand_slots + p.spill_entries)) {
-              err = ST_CAND_OVERFLOW;
-              pm = 0;
-              break;
-            }
-            if (cand_n < (int)p.cand_slots) {
-              coop_push(cand, cand_n, fnv_stl::Entry{-di, idi}, lane, ph, 11);
-            } else {
-              __threadfence_block();
-              coop_push(cand_big, cand_n, fnv_stl::Entry{-di, idi}, lane, ph, 11);
-              __threadfence_block();
-            }
-            coop_push(nbr, nbr_n, fnv_stl::Entry{di, idi}, lane, ph, 12);
-            if (nbr_n + 1 > B) coop_pop(nbr, nbr_n + 1, lane, ph, 13);
-            cand_n++;
-            if (nbr_n < B) nbr_n++;
-            max_dist = rfl(nbr.get(0).key);
+        constexpr int VPW = WAVE / G;
+        const int v = lane / G;
+        const bool group_leader = (lane % G) == 0;
+        for (int base = 0; base < n; base += VPW * PU) {
+          // ---- distances of this batch, kept in registers: slot = base + pu*VPW + v lives in lane v*G
+          uint32_t cid[PU];
+          bool cval[PU];
+          float cd[PU];
+#pragma unroll
+          for (int pu = 0; pu < PU; pu++) {
+            const int slot = base + pu * VPW + v;
+            cval[pu] = slot < n;
+            cid[pu] = cval[pu] ? stage_ids[slot] : 0u;
           }
+          const int npass = min(PU, (n - base + VPW - 1) / VPW);
+          batch_dists<T, METRIC, G, CU, FULL>(p, qlds, cid, cval, npass, cd, lane);
+          PH_MARK(5);
+
+          // ---- admissions in link order (Index.h:667-705).  Superset filter first: max_dist never grows
+          // once the beam is full, so whatever fails here would also fail the sequential test.
+#pragma unroll
+          for (int pu = 0; pu < PU; pu++) {
+            if (pu >= npass) break;
+            unsigned long long pm = __ballot(group_leader && cval[pu] && (nbr_n < B || cd[pu] < max_dist));
+            while (pm) {
+              const int i = __ffsll((long long)pm) - 1;
+              pm &= pm - 1;
+              const float di = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cd[pu]), i));
+              const uint32_t idi = (uint32_t)__builtin_amdgcn_readlane((int)cid[pu], i);
+              if (nbr_n < B || di < max_dist) {  // Index.h:693
+                if (cand_n >= (int)(p.cand_slots + p.spill_entries)) {
+                  err = ST_CAND_OVERFLOW;
+                  pm = 0;
+                  break;
+                }
+                if (cand_n < (int)p.cand_slots) {
+                  coop_push(cand, cand_n, fnv_stl::Entry{-di, idi}, lane, ph, 11);
+                } else {
+                  __threadfence_block();
+                  coop_push(cand_big, cand_n, fnv_stl::Entry{-di, idi}, lane, ph, 11);
+                  __threadfence_block();
+                }
+                coop_push(nbr, nbr_n, fnv_stl::Entry{di, idi}, lane, ph, 12);
+                if (nbr_n + 1 > B) coop_pop(nbr, nbr_n + 1, lane, ph, 13);
+                cand_n++;
+                if (nbr_n < B) nbr_n++;
+                max_dist = rfl(nbr.get(0).key);
+              }
+            }
+            if (err) break;
+          }
+          PH_MARK(6);
+          if (err) break;
         }
-        __syncthreads();
-        PH_MARK(6);
+        wave_sync();  // stage_ids is rewritten by the next row chunk
         if (err) break;
       }
       if (err) break;
@@ -904,22 +955,28 @@ struct KernelCfg {
 const KernelCfg kCfgs[] = {{8, 1}, {8, 2}, {8, 4}, {16, 4}, {32, 4}, {64, 4}};
 constexpr int kNumCfgs = 6;
 
-template <typename T, int METRIC>
+template <typename T, int METRIC, bool FULL>
 kernel_fn pick_cfg(int c) {
   switch (c) {
-    case 0: return beam_search_kernel<T, METRIC, 8, 1>;
-    case 1: return beam_search_kernel<T, METRIC, 8, 2>;
-    case 2: return beam_search_kernel<T, METRIC, 8, 4>;
-    case 3: return beam_search_kernel<T, METRIC, 16, 4>;
-    case 4: return beam_search_kernel<T, METRIC, 32, 4>;
-    default: return beam_search_kernel<T, METRIC, 64, 4>;
+    case 0: return beam_search_kernel<T, METRIC, 8, 1, FULL>;
+    case 1: return beam_search_kernel<T, METRIC, 8, 2, FULL>;
+    case 2: return beam_search_kernel<T, METRIC, 8, 4, FULL>;
+    case 3: return beam_search_kernel<T, METRIC, 16, 4, FULL>;
+    case 4: return beam_search_kernel<T, METRIC, 32, 4, FULL>;
+    default: return beam_search_kernel<T, METRIC, 64, 4, FULL>;
   }
 }
 
-kernel_fn pick_kernel(int dtype, int metric, int cfg) {
-  if (dtype == FNV_DTYPE_FLOAT32) return metric == FNV_METRIC_L2 ? pick_cfg<float, FNV_METRIC_L2>(cfg) : pick_cfg<float, FNV_METRIC_IP>(cfg);
-  if (dtype == FNV_DTYPE_UINT8) return metric == FNV_METRIC_L2 ? pick_cfg<uint8_t, FNV_METRIC_L2>(cfg) : pick_cfg<uint8_t, FNV_METRIC_IP>(cfg);
-  return metric == FNV_METRIC_L2 ? pick_cfg<int8_t, FNV_METRIC_L2>(cfg) : pick_cfg<int8_t, FNV_METRIC_IP>(cfg);
+template <typename T>
+kernel_fn pick_metric(int metric, int cfg, bool full) {
+  if (metric == FNV_METRIC_L2) return full ? pick_cfg<T, FNV_METRIC_L2, true>(cfg) : pick_cfg<T, FNV_METRIC_L2, false>(cfg);
+  return full ? pick_cfg<T, FNV_METRIC_IP, true>(cfg) : pick_cfg<T, FNV_METRIC_IP, false>(cfg);
+}
+
+kernel_fn pick_kernel(int dtype, int metric, int cfg, bool full) {
+  if (dtype == FNV_DTYPE_FLOAT32) return pick_metric<float>(metric, cfg, full);
+  if (dtype == FNV_DTYPE_UINT8) return pick_metric<uint8_t>(metric, cfg, full);
+  return pick_metric<int8_t>(metric, cfg, full);
 }
 
 }  // namespace
@@ -934,7 +991,7 @@ struct fnv_index_s {
   int32_t* d_labels = nullptr;
   int num_cus = 0;
   // options
-  int64_t visited_factor = 22, visited_slots = 0, cand_factor = 2, cand_slots = 0, spill_entries = 16384,
+  int64_t visited_factor = 32, visited_slots = 0, cand_factor = 2, cand_slots = 0, spill_entries = 16384,
           blocks_per_cu = 0, visited_wide = 0;
   // workspace (grown on demand)
   uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status
@@ -1203,7 +1260,7 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
     uint32_t nbits = 1;
     while (nbits < 32 && (1ull << nbits) < ix->n_nodes) nbits++;
     uint64_t want = ix->visited_slots ? (uint64_t)ix->visited_slots
-                                      : (uint64_t)ix->visited_factor * (uint64_t)p.B + 640;
+                                      : (uint64_t)ix->visited_factor * (uint64_t)p.B + 256;
     want = std::max<uint64_t>(want, 256);
     uint32_t slots = 256;
     for (uint32_t base = 256;; base <<= 1) {  // candidates in increasing order: 2^j, 3*2^(j-1), 2^(j+1), ...
@@ -1261,7 +1318,8 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
     return fail(FNV_ERR_INVALID, "ef_search too large for the on-chip beam state (needs " + std::to_string(lds_bytes) +
                                      " bytes of LDS, 163840 available); lower ef_search or the *_slots options");
 
-  kernel_fn kern = pick_kernel(ix->dtype, ix->metric, cfg);
+  const bool full = (p.nchunks % per_iter) == 0;  // rows are whole spans: the lean FULL kernels apply
+  kernel_fn kern = pick_kernel(ix->dtype, ix->metric, cfg, full);
   HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   int bpc = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, WAVE, lds_bytes));
