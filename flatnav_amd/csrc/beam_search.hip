@@ -184,21 +184,19 @@ __device__ __forceinline__ void coop_push(H& h, int n, fnv_stl::Entry v, int lan
   v.val = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.val);
   const uint32_t m1 = (uint32_t)n + 1u;
   const int depth = 31 - __clz((int)m1);  // number of ancestors of index n
-  fnv_stl::Entry anc = v;
-  bool up = false;
-  if (lane < depth) {
-    anc = h.get((int)(m1 >> (lane + 1)) - 1);
-    up = anc.key < v.key;
-  }
-  const unsigned long long run = __ballot(up);
+  // lane j looks at ancestor a_{j+1} = (m1 >> (j+1)) - 1; lanes past the root re-read the root (harmless)
+  const uint32_t sh = (uint32_t)min(lane + 1, depth);
+  const fnv_stl::Entry anc = h.get(max((int)(m1 >> sh) - 1, 0));
+  const unsigned long long run = __ballot(lane < depth && anc.key < v.key);
   const int t = __ffsll((long long)~run) - 1;  // lanes >= depth vote false, so t <= depth
-  if (lane < t) h.set((int)(m1 >> lane) - 1, anc);
-  if (lane == t) h.set((int)(m1 >> t) - 1, v);
+  if (lane <= t) h.set((int)(m1 >> lane) - 1, lane < t ? anc : v);  // lanes < t: ancestor one level down; lane t: v
   wave_sync();
   ph.mark(phbase);
 }
 
-template <class H>
+// KEEP_TOP: also park the removed top in the vacated slot, as std::pop_heap does (only the result tail
+// needs that; the beam loop never looks at the slot again).
+template <bool KEEP_TOP, class H>
 __device__ __forceinline__ void coop_pop(H& h, int n, int lane, PhaseTimer& ph, int phbase) {
   n = __builtin_amdgcn_readfirstlane(n);
   if (n <= 1) return;  // std::pop_heap does nothing for a single element
@@ -209,7 +207,8 @@ __device__ __forceinline__ void coop_pop(H& h, int n, int lane, PhaseTimer& ph, 
   }
   const int len = n - 1;
   const fnv_stl::Entry v_raw = h.get(len);  // same address in all lanes (broadcast); used in phase 3
-  const fnv_stl::Entry top = h.get(0);
+  fnv_stl::Entry top = v_raw;
+  if (KEEP_TOP) top = h.get(0);
   const int two = (len - 1) / 2;  // nodes [0, two) have two children
   // phase 1: for every two-child node, does the RIGHT child win (i.e. NOT right.key < left.key)?
   // phase 2: walk root -> leaf in 1-based numbering (node m = index + 1; children 2m, 2m+1): the
@@ -235,9 +234,13 @@ __device__ __forceinline__ void coop_pop(H& h, int n, int lane, PhaseTimer& ph, 
     const unsigned long long r0 = __ballot(lane < two && !w0), r1 = __ballot(WAVE + lane < two && !w1);
     const unsigned long long r2 = __ballot(2 * WAVE + lane < two && !w2), r3 = __ballot(3 * WAVE + lane < two && !w3);
     ph.mark(phbase);
+    while (m <= 64u) {  // nodes 0..63 (levels 0-5, two > 63 here): first mask only
+      m = (m << 1) | (uint32_t)((r0 >> (m - 1)) & 1ull);
+      L++;
+    }
     while (m <= two1) {
       const uint32_t i0 = m - 1, w = i0 >> 6;
-      const unsigned long long rw = w == 0 ? r0 : w == 1 ? r1 : w == 2 ? r2 : r3;
+      const unsigned long long rw = w == 1 ? r1 : w == 2 ? r2 : r3;
       m = (m << 1) | (uint32_t)((rw >> (i0 & 63)) & 1ull);
       L++;
     }
@@ -282,9 +285,8 @@ __device__ __forceinline__ void coop_pop(H& h, int n, int lane, PhaseTimer& ph, 
   }
   const unsigned long long fail = ~__ballot(back) & ((1ull << L) - 1ull);  // L <= 31
   const int jf = fail ? 63 - __clzll((long long)fail) : -1;  // deepest level whose move survives
-  if (lane <= jf) h.set(my_p, val);
-  if (lane == jf + 1) h.set(my_p, v);
-  if (lane == 0) h.set(len, top);  // std::pop_heap parks the old top in the vacated slot
+  if (lane <= jf + 1) h.set(my_p, lane <= jf ? val : v);
+  if (KEEP_TOP && lane == 0) h.set(len, top);  // std::pop_heap parks the old top in the vacated slot
   wave_sync();
   ph.mark(phbase + 2);
 }
@@ -663,10 +665,10 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
       uint32_t row_id = EMPTY_ID;
       if (lane < M) row_id = p.links[(uint64_t)(uint32_t)node * p.M + lane];
       if (cand_n <= (int)p.cand_slots) {
-        coop_pop(cand, cand_n, lane, ph, 8);
+        coop_pop<false>(cand, cand_n, lane, ph, 8);
       } else {  // part of the heap lives in the HBM spill area
         __threadfence_block();
-        coop_pop(cand_big, cand_n, lane, ph, 8);
+        coop_pop<false>(cand_big, cand_n, lane, ph, 8);
         __threadfence_block();
       }
       cand_n--;
@@ -744,7 +746,7 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
                   __threadfence_block();
                 }
                 coop_push(nbr, nbr_n, fnv_stl::Entry{di, idi}, lane, ph, 12);
-                if (nbr_n + 1 > B) coop_pop(nbr, nbr_n + 1, lane, ph, 13);
+                if (nbr_n + 1 > B) coop_pop<false>(nbr, nbr_n + 1, lane, ph, 13);
                 cand_n++;
                 if (nbr_n < B) nbr_n++;
                 max_dist = rfl(nbr.get(0).key);
@@ -786,7 +788,7 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
     __syncthreads();
     if (any_tie) {
       // Exact replay of the reference's tail: pop everything (descending), std::sort ascending.
-      for (int m = n; m > 1; m--) coop_pop(nbr, m, lane, ph, 7);  // leaves nbr[] ascending
+      for (int m = n; m > 1; m--) coop_pop<true>(nbr, m, lane, ph, 7);  // leaves nbr[] ascending
       __syncthreads();
       for (int i = lane; i < n; i += WAVE) res[i] = nbr.p[n - 1 - i];  // pop order = descending
       __syncthreads();
@@ -854,7 +856,7 @@ __global__ __launch_bounds__(WAVE) void heap_microbench_kernel(int size, int ite
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   unsigned long long t1 = clock64();
   for (int it = 0; it < iters; it++) {
-    coop_pop(h, n + 1, lane, ph, 12);
+    coop_pop<true>(h, n + 1, lane, ph, 12);
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   unsigned long long t2 = clock64();
