@@ -59,9 +59,13 @@ def main() -> None:
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--M", type=int, default=32)
     ap.add_argument("--efc", type=int, default=100)
-    ap.add_argument("--ef", type=int, default=100)
+    ap.add_argument("--ef", type=int, default=0,
+                    help="ef_search; 0 = the metric's rule: smallest ef of --ef-sweep with recall@10 >= 0.95")
+    ap.add_argument("--ef-sweep", default="50,60,75,100,150,200,400")
     ap.add_argument("--K", type=int, default=10)
     ap.add_argument("--build-threads", type=int, default=0)
+    ap.add_argument("--dtype", default="float32", choices=["float32", "uint8"],
+                    help="index element type (uint8: the same integer-valued data stored as bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="C-ABI option name=value")
     args = ap.parse_args()
@@ -87,13 +91,17 @@ def main() -> None:
     from flatnav_amd import datasets as ds
     from flatnav_amd import hip
 
-    N, NQ, DIM, M, K, EF = args.n, args.nq, args.dim, args.M, args.K, args.ef
-    hw = os.cpu_count() or 1
+    N, NQ, DIM, M, K = args.n, args.nq, args.dim, args.M, args.K
+    hw = ds.effective_cpus()  # honours the cgroup CPU quota (16 on the MI355X boxes, 256 CPUs visible)
 
     # ---- data: every rank generates the same base stream; queries differ per rank (sharding) ----
     t0 = time.time()
     X, Q_all = ds.sift_like(N, NQ * world, dim=DIM)
     Q = np.ascontiguousarray(Q_all[rank * NQ:(rank + 1) * NQ])
+    DT = args.dtype
+    ESIZE = 4 if DT == "float32" else 1
+    if DT == "uint8":
+        X, Q = X.astype(np.uint8), Q.astype(np.uint8)
     log("[rank %d] data %.1fs" % (rank, time.time() - t0))
 
     # ---- index: rank 0 builds with the product's host builder, uploads, broadcasts ---------------
@@ -101,19 +109,19 @@ def main() -> None:
     index = None
     if rank == 0:
         t0 = time.time()
-        index = flatnav.index.create(distance_type="l2", index_data_type=flatnav.data_type.DataType.float32,
+        index = flatnav.index.create(distance_type="l2", index_data_type=getattr(flatnav.data_type.DataType, DT),
                                      dim=DIM, dataset_size=N, max_edges_per_node=M)
-        threads = args.build_threads or max(1, min(hw, 192) // (1 if world == 1 else 1))
+        threads = args.build_threads or max(1, min(hw + hw // 2, os.cpu_count() or 1))
         index.set_num_threads(threads)
         index.add(data=X, ef_construction=args.efc)
         log("[rank 0] host build: %d nodes, %d threads, %.1fs" % (N, threads, time.time() - t0))
         t0 = time.time()
         blob = np.asarray(index._raw_blob())
-        dev = hip.DeviceIndex.upload(blob, index._node_size_bytes, index._data_size_bytes, M, N, "float32", "l2", DIM,
+        dev = hip.DeviceIndex.upload(blob, index._node_size_bytes, index._data_size_bytes, M, N, DT, "l2", DIM,
                                      device=local_rank)
         log("[rank 0] upload + re-layout to HBM: %.2fs" % (time.time() - t0))
     else:
-        dev = hip.DeviceIndex.alloc(M, N, "float32", "l2", DIM, device=local_rank)
+        dev = hip.DeviceIndex.alloc(M, N, DT, "l2", DIM, device=local_rank)
     if world > 1:
         from flatnav_amd import multigpu
 
@@ -132,6 +140,48 @@ def main() -> None:
     d_nd = torch.zeros(NQ, dtype=torch.int64, device="cuda")
     d_nh = torch.zeros(NQ, dtype=torch.int64, device="cuda")
     stream = torch.cuda.current_stream()
+
+    # ---- exact ground truth for recall@10 (brute force on the GPU, first 1000 queries of this rank) ----
+    nrec = min(1000, NQ)
+    xt = torch.from_numpy(X).cuda().float()
+    qt = dq[:nrec].float()
+    xn = (xt * xt).sum(1)
+    gt = torch.empty((nrec, K), dtype=torch.int64, device="cuda")
+    for s0 in range(0, nrec, 250):
+        d2 = xn[None, :] - 2.0 * (qt[s0:s0 + 250] @ xt.T)
+        gt[s0:s0 + 250] = torch.topk(d2, K, dim=1, largest=False).indices
+    gt = gt.cpu().numpy()
+    del xt, xn, qt
+    torch.cuda.empty_cache()
+
+    def recall_at(ef):
+        dev.search_device(dq.data_ptr(), nrec, K, ef, 100, d_dist.data_ptr(), d_lab.data_ptr(), stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        dev.status()
+        return ds.recall_at_k(d_lab[:nrec].cpu().numpy(), gt)
+
+    # ---- ef_search: the metric is QPS at recall@10 >= 0.95 -> smallest swept ef that reaches it (rank 0 decides) ----
+    sweep = {}
+    if args.ef > 0:
+        EF = args.ef
+    else:
+        EF = 0
+        for ef in sorted(int(x) for x in args.ef_sweep.split(",")):
+            if rank == 0:
+                sweep[ef] = round(recall_at(ef), 4)
+                ok = sweep[ef] >= 0.95
+            else:
+                ok = False
+            if dist is not None:
+                flag = torch.tensor([1 if ok else 0], device="cuda")
+                dist.broadcast(flag, src=0)
+                ok = bool(flag.item())
+            if ok:
+                EF = ef
+                break
+        if EF == 0:
+            EF = max(int(x) for x in args.ef_sweep.split(","))
+        log("[rank %d] ef sweep %s -> ef_search=%d" % (rank, sweep, EF))
 
     def step():
         dev.search_device(dq.data_ptr(), NQ, K, EF, 100, d_dist.data_ptr(), d_lab.data_ptr(), d_cnt.data_ptr(),
@@ -167,24 +217,14 @@ def main() -> None:
     nh = d_nh.cpu().numpy().astype(np.int64)
     step_nodes = max(1, N // 100)
     n_scan = (N + step_nodes - 1) // step_nodes
-    bytes_launch = int(((n_scan + nd) * DIM * 4 + nh * M * 4 + K * 4).sum())
+    bytes_launch = int(((n_scan + nd) * DIM * ESIZE + nh * M * 4 + K * 4).sum())
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
     achieved = bytes_launch / avg_kernel_s / 1e9
 
     out = None
     if rank == 0:
         labels = d_lab.cpu().numpy()
-        # recall@10 against exact brute force on the GPU (first 1000 queries of this rank)
-        nrec = min(1000, NQ)
-        xt = torch.from_numpy(X).cuda()
-        qt = dq[:nrec]
-        xn = (xt * xt).sum(1)
-        gt = torch.empty((nrec, K), dtype=torch.int64, device="cuda")
-        for s in range(0, nrec, 250):
-            d2 = xn[None, :] - 2.0 * (qt[s:s + 250] @ xt.T)
-            gt[s:s + 250] = torch.topk(d2, K, dim=1, largest=False).indices
-        recall = ds.recall_at_k(labels[:nrec], gt.cpu().numpy())
-        del xt, xn
+        recall = ds.recall_at_k(labels[:nrec], gt)
         geom = dev.launch_geometry()
         # informational: the host-buffer entry point (pageable H2D of the queries + kernel + D2H of results)
         t0 = time.perf_counter()
@@ -204,13 +244,16 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if DT == "float32" else "u8",
             "data": "synthetic",
             "config": {
-                "workload": "SIFT-1M stand-in (S1 int-lowrank, SURVEY.md 8d): %d x %d float32 L2, M=%d, "
+                "workload": "SIFT-1M stand-in (S1 int-lowrank, SURVEY.md 8d): %d x %d %s L2, M=%d, "
                             "ef_construction=%d, ef_search=%d, K=%d, %d batched queries per GPU, index in HBM"
-                            % (N, DIM, M, args.efc, EF, K, NQ),
+                            % (N, DIM, DT, M, args.efc, EF, K, NQ),
                 "recall_at_10": round(recall, 4),
+                "ef_search": EF,
+                "ef_selection": ("fixed by --ef" if args.ef > 0 else
+                                 "smallest ef of the sweep with recall@10 >= 0.95 (SURVEY.md 8d); recalls: %s" % sweep),
                 "parallelism": "index replicated x%d, queries sharded" % world,
                 "mean_dist_evals_per_query": float(nd.mean()),
                 "mean_hops_per_query": float(nh.mean()),
@@ -219,7 +262,8 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "beam_search_kernel<float, 0, 8, 4>",
+                "kernel": "beam_search_kernel<%s, L2, G=8, CU=%d, FULL>" % ("float" if DT == "float32" else "uint8_t",
+                                                                              4 if DT == "float32" else 1),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
@@ -230,7 +274,7 @@ def main() -> None:
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(index, Q, K, EF, hw, labels)
+            out["cpu_baseline"] = cpu_baseline(index, Q, K, EF, hw, labels, DT)
         del index
     if dist is not None:
         dist.barrier()
@@ -239,7 +283,7 @@ def main() -> None:
         print(json.dumps(out), flush=True)
 
 
-def cpu_baseline(index, Q, K, EF, hw, gpu_labels):
+def cpu_baseline(index, Q, K, EF, hw, gpu_labels, dtype="float32"):
     """The CPU oracle (restated reference search, oracle/) on the same graph and queries, all host
     threads, bounded to roughly 10-20 s.  Also re-checks GPU == CPU ids on the sample."""
     from oracle import oracle as orc
@@ -247,7 +291,7 @@ def cpu_baseline(index, Q, K, EF, hw, gpu_labels):
     orc.build()
     blob = np.asarray(index._raw_blob())
     n = int(index._cur_num_nodes)
-    o = orc.OracleIndex.from_blob("l2", "float32", Q.shape[1], n, n, index.max_edges_per_node, blob)
+    o = orc.OracleIndex.from_blob("l2", dtype, Q.shape[1], n, n, index.max_edges_per_node, blob)
     kind_note = "oracle port, own AVX2 distance"
     if o.use_reference_distance(True):
         kind_note = "oracle port of Index::search driving the reference's own compiled AVX-512 distance kernel (oracle/_ref)"

@@ -101,3 +101,25 @@ def recall_at_k(found: np.ndarray, truth: np.ndarray) -> float:
     for f, t in zip(found, truth):
         hits += len(set(f[:k].tolist()) & set(t.tolist()))
     return hits / (k * len(truth))
+
+
+def effective_cpus() -> int:
+    """CPUs this process can really use: the scheduler affinity capped by the cgroup CPU quota
+    (cpu.max = "<quota> <period>").  On the MI355X boxes 256 CPUs are visible but the quota is 16."""
+    import math
+    import os
+
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            pr = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, math.ceil(q / pr)))
+        except (OSError, ValueError):
+            pass
+    return n

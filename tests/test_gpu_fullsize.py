@@ -19,7 +19,7 @@ def test_sift1m_shape_properties_and_parity(oracle_mod):
     N, NQ, K, EF = 1_000_000, 10_000, 10, 100
     X, Q = ds.sift_like(N, NQ)
     index = flatnav.index.create("l2", 128, N, 32)
-    index.set_num_threads(min(192, os.cpu_count() or 1))
+    index.set_num_threads(min(24, os.cpu_count() or 1))
     index.add(X, 100)
     d, l = index.search(Q, K, EF)
     # (1) shape / order / range

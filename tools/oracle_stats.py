@@ -12,7 +12,7 @@ from oracle import oracle as orc
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 X, Q = ds.sift_like(n, 4000)
 index = flatnav.index.create("l2", 128, n, 32)
-index.set_num_threads(min(192, os.cpu_count()))
+index.set_num_threads(min(24, os.cpu_count()))
 t0 = time.time(); index.add(X, 100); print("build %.1fs" % (time.time() - t0), flush=True)
 o = orc.OracleIndex.from_blob("l2", "float32", 128, n, n, 32, np.asarray(index._raw_blob()))
 for ef in (50, 100, 200, 400):

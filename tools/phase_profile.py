@@ -40,7 +40,7 @@ def main():
 
     X, Q = ds.sift_like(args.n, args.nq)
     index = flatnav.index.create("l2", 128, args.n, 32)
-    index.set_num_threads(min(192, os.cpu_count()))
+    index.set_num_threads(min(24, os.cpu_count()))
     t0 = time.time()
     index.add(X, 100)
     print("build %.1fs" % (time.time() - t0), flush=True)
