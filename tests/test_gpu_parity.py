@@ -173,3 +173,31 @@ def test_argument_errors(oracle_mod, hipmod):
     bad[0, ix.data_size:ix.data_size + 4] = np.array([10 ** 6], dtype=np.uint32).view(np.uint8)
     with pytest.raises(RuntimeError):
         hipmod.DeviceIndex.upload(bad, ix.node_size, ix.data_size, ix.M, 300, "float32", "l2", 12)
+
+
+@pytest.mark.parametrize("M", [48, 64, 80, 130])
+def test_wide_link_rows(oracle_mod, hipmod, M):
+    # rows wider than one wavefront are expanded 64 links at a time, still in link order
+    rng = np.random.default_rng(M)
+    X = rng.integers(0, 256, (3000, 32)).astype(np.float32)
+    Q = rng.integers(0, 256, (300, 32)).astype(np.float32)
+    ix = _build(oracle_mod, "l2", "float32", X, M, efc=80)
+    dev = _upload(hipmod, ix)
+    _assert_exact(ix.search(Q, 10, 80, stats=True), dev.search(Q, 10, 80, stats=True))
+
+
+@pytest.mark.parametrize("ef,K", [(600, 10), (1000, 200), (300, 300)])
+def test_large_beams(oracle_mod, hipmod, ef, K):
+    # big ef: visited table of tens of KB, heaps beyond the 64- and 256-node mask fast paths
+    X, Q = ds.sift_like(20000, 60)
+    ix = _build(oracle_mod, "l2", "float32", X, 32)
+    dev = _upload(hipmod, ix)
+    _assert_exact(ix.search(Q, K, ef, stats=True), dev.search(Q, K, ef, stats=True))
+
+
+def test_beam_too_large_for_lds_is_an_error(oracle_mod, hipmod):
+    X, Q = ds.sift_like(3000, 4)
+    ix = _build(oracle_mod, "l2", "float32", X, 16, efc=64)
+    dev = _upload(hipmod, ix)
+    with pytest.raises(ValueError):
+        dev.search(Q, 10, 20000)
