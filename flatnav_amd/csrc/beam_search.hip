@@ -38,7 +38,10 @@ namespace {
 
 constexpr uint32_t EMPTY_ID = 0xFFFFFFFFu;
 constexpr int WAVE = 64;
-constexpr int PU = 4;  // vector "passes" whose loads are issued back to back before any use
+#ifndef FNV_PU
+#define FNV_PU 4
+#endif
+constexpr int PU = FNV_PU;  // vector "passes" whose loads are issued back to back before any use
 #ifndef FNV_MIN_WAVES_PER_SIMD
 #define FNV_MIN_WAVES_PER_SIMD 3  // __launch_bounds__ 2nd argument: register budget 512/3 per lane
 #endif
@@ -146,8 +149,14 @@ struct PhaseTimer {
   __device__ __forceinline__ void flush(unsigned long long*, int) {}
 };
 #endif
+// -DFNV_ASM_MARKS drops named comments into the ISA (tools/isa_regions.py counts instructions between them)
+#ifdef FNV_ASM_MARKS
+#define ISA_MARK(name) asm volatile("; ##MARK " name ::: "memory")
+#else
+#define ISA_MARK(name)
+#endif
 #define PH_DECL PhaseTimer ph; ph.start();
-#define PH_MARK(i) ph.mark(i)
+#define PH_MARK(i) do { ph.mark(i); ISA_MARK("phase" #i); } while (0)
 #define PH_FLUSH ph.flush(p.phase_cycles, lane)
 
 // ---------------------------------------------------------------------------------------------
