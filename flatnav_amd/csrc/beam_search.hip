@@ -840,7 +840,7 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
   }
 }
 
-#ifdef FNV_PHASE_TIMING
+#if defined(FNV_PHASE_TIMING) || defined(FNV_MICROBENCH)
 // Developer micro-benchmark (profiling builds only): cycles per cooperative heap operation on an
 // LDS heap of `size` entries, `blocks` single-wave workgroups running concurrently.
 __global__ __launch_bounds__(WAVE) void heap_microbench_kernel(int size, int iters, unsigned long long* out) {
@@ -1002,7 +1002,7 @@ struct fnv_index_s {
   int32_t* d_labels = nullptr;
   int num_cus = 0;
   // options
-  int64_t visited_factor = 32, visited_slots = 0, cand_factor = 2, cand_slots = 0, spill_entries = 16384,
+  int64_t visited_factor = 27, visited_slots = 0, cand_factor = 2, cand_slots = 0, spill_entries = 16384,
           blocks_per_cu = 0, visited_wide = 0;
   // workspace (grown on demand)
   uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status
@@ -1271,7 +1271,7 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
     uint32_t nbits = 1;
     while (nbits < 32 && (1ull << nbits) < ix->n_nodes) nbits++;
     uint64_t want = ix->visited_slots ? (uint64_t)ix->visited_slots
-                                      : (uint64_t)ix->visited_factor * (uint64_t)p.B + 256;
+                                      : (uint64_t)ix->visited_factor * (uint64_t)p.B + 600;
     want = std::max<uint64_t>(want, 256);
     uint32_t slots = 256;
     for (uint32_t base = 256;; base <<= 1) {  // candidates in increasing order: 2^j, 3*2^(j-1), 2^(j+1), ...

@@ -94,8 +94,8 @@ int fnv_index_info(fnv_index_t index, uint64_t info[8]);
 int fnv_index_free(fnv_index_t index);
 
 /* Tuning / test knobs (all optional).  Names:
- *   "visited_factor"  LDS visited-table slots = visited_factor * beam width + 256, rounded up to 2^j or
- *                     3*2^j (default 32)
+ *   "visited_factor"  LDS visited-table slots = visited_factor * beam width + 600, rounded up to 2^j or
+ *                     3*2^j (default 27)
  *   "visited_slots"   force the LDS visited-table size (2^j or 3*2^j; 0 = from factor)
  *   "cand_factor"     LDS candidate-heap capacity = cand_factor * beam width + 192 (default 2)
  *   "cand_slots"      force the LDS candidate-heap capacity (0 = from factor)
