@@ -63,6 +63,11 @@ struct SearchParams {
   int32_t* status;          // sticky error flag for the whole launch
   uint32_t* ovf_bitmap;     // [nslots][bitmap_words] visited-set spill (all zero between queries)
   unsigned long long* cand_spill;  // [nslots][spill_entries]
+  const uint32_t* entry_node;  // [nq] from entry_scan_kernel (null: scan inside the search kernel)
+  const float* entry_dist;     // [nq]
+  uint32_t* entry_node_out;    // entry_scan_kernel outputs
+  float* entry_dist_out;
+  uint32_t scan_tile_rows, scan_tile_stride;  // entry_scan_kernel: LDS tile geometry
   unsigned long long* phase_cycles;  // [16] profiling build only (FNV_PHASE_TIMING), else null
   uint64_t n_nodes;
   uint32_t nq, M, dim, row_bytes, nchunks, q_chunks;
@@ -401,18 +406,20 @@ struct Dist<int8_t, METRIC> : DistInt<int8_t, METRIC> {};
 // PU*CU loads of an inner iteration are issued before the first use.  Results stay in registers: every
 // lane of a group ends with the group's distance in out[pu].
 // ---------------------------------------------------------------------------------------------
+// Rows are addressed as rows + id * row_stride: the HBM vector table in the search kernel, an LDS tile in the
+// entry-scan kernel (same arithmetic and summation order in both, so their distances agree bit for bit).
 template <typename T, int METRIC, int G, int CU, bool FULL>
-__device__ __forceinline__ void batch_dists(const SearchParams& p, const uint4* qlds, const uint32_t (&id)[PU],
-                                            const bool (&valid)[PU], int npass, float (&out)[PU], int lane) {
+__device__ __forceinline__ void batch_dists(const uint8_t* rows, uint32_t row_stride, int nchunks, const uint4* qlds,
+                                            const uint32_t (&id)[PU], const bool (&valid)[PU], int npass,
+                                            float (&out)[PU], int lane) {
   typedef Dist<T, METRIC> D;
   typedef typename D::acc_t acc_t;
   const int g = lane % G;
-  const int nchunks = (int)p.nchunks;
   acc_t acc[PU];
   const uint8_t* rowp[PU];
 #pragma unroll
   for (int pu = 0; pu < PU; pu++) {
-    rowp[pu] = p.vectors + (uint64_t)(valid[pu] ? id[pu] : 0u) * p.row_bytes;
+    rowp[pu] = rows + (uint64_t)(valid[pu] ? id[pu] : 0u) * row_stride;
     acc[pu] = D::zero();
   }
   if (FULL) {
@@ -568,6 +575,119 @@ __device__ __forceinline__ float rfl(float v) { return __int_as_float(__builtin_
 // ---------------------------------------------------------------------------------------------
 // The search kernel.
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Entry-point selection (Index.h:845-870): argmin over nodes 0, s, 2s, ... ; strict '<', so the FIRST minimum
+// wins.  Per lane the node index only grows, so '<' keeps the earliest; across lanes the tie goes to the
+// smaller index.  `rows`/`stride` address row j of the scan set (HBM: j*step-th vector; LDS tile: j-th row).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int METRIC, int G, int CU, bool FULL>
+__device__ __forceinline__ void scan_rows(const uint8_t* rows, uint32_t stride_rows, uint32_t id_mul, int nchunks,
+                                          const uint4* qlds, uint32_t count, uint32_t j_base, int lane, float& best_d,
+                                          uint32_t& best_j) {
+  constexpr int VPW = WAVE / G;
+  const int v = lane / G;
+  for (uint32_t j0 = 0; j0 < count; j0 += VPW * PU) {
+    uint32_t sid[PU];
+    bool sval[PU];
+    float sd[PU];
+#pragma unroll
+    for (int pu = 0; pu < PU; pu++) {
+      const uint32_t j = j0 + pu * VPW + v;
+      sval[pu] = j < count;
+      sid[pu] = j * id_mul;
+    }
+    const int npass = (int)min((uint32_t)PU, (count - j0 + VPW - 1) / VPW);
+    batch_dists<T, METRIC, G, CU, FULL>(rows, stride_rows, nchunks, qlds, sid, sval, npass, sd, lane);
+#pragma unroll
+    for (int pu = 0; pu < PU; pu++) {
+      if (sval[pu] && sd[pu] < best_d) {  // strict '<': first minimum wins (Index.h:864)
+        best_d = sd[pu];
+        best_j = j_base + j0 + pu * VPW + v;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void wave_argmin(float& best_d, uint32_t& best_j) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const float od = __shfl_xor(best_d, o, WAVE);
+    const uint32_t oj = __shfl_xor(best_j, o, WAVE);
+    if (od < best_d || (od == best_d && oj < best_j)) {
+      best_d = od;
+      best_j = oj;
+    }
+  }
+}
+
+// In-kernel variant (used when the batch kernel is switched off): scan straight from HBM / L2.
+template <typename T, int METRIC, int G, int CU, bool FULL>
+__device__ __forceinline__ uint32_t scan_entry_points(const SearchParams& p, const uint4* qlds, int lane, float& best_d) {
+  best_d = std::numeric_limits<float>::max();
+  uint32_t best_j = 0;
+  scan_rows<T, METRIC, G, CU, FULL>(p.vectors, p.row_bytes, p.scan_step, (int)p.nchunks, qlds, p.n_scan, 0u, lane,
+                                    best_d, best_j);
+  wave_argmin(best_d, best_j);
+  return best_j * p.scan_step;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K0: entry points for the whole batch.  Every query scans the SAME ceil(N/step) nodes, so a workgroup
+// (4 waves) stages them once in LDS (tiles of scan_tile_rows rows, row stride padded by 16 bytes against
+// bank conflicts) and runs SCAN_QPB queries against the tile; distances use the very same batch_dists code
+// as the search kernel, so entry_dist equals what the search kernel would have computed, bit for bit.
+// ---------------------------------------------------------------------------------------------
+constexpr int SCAN_WAVES = 4;
+constexpr int SCAN_QPB = 32;
+
+template <typename T, int METRIC, int G, int CU, bool FULL>
+__global__ __launch_bounds__(SCAN_WAVES* WAVE) void entry_scan_kernel(const SearchParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
+  const uint32_t qbytes = p.q_chunks * 16u;
+  uint4* qlds = reinterpret_cast<uint4*>(smem + wave * qbytes);
+  float* bd = reinterpret_cast<float*>(smem + SCAN_WAVES * qbytes);
+  uint32_t* bj = reinterpret_cast<uint32_t*>(bd + SCAN_QPB);
+  uint8_t* tile = reinterpret_cast<uint8_t*>(bj + SCAN_QPB);
+  const uint32_t q0 = blockIdx.x * SCAN_QPB;
+  const uint32_t nqb = min((uint32_t)SCAN_QPB, p.nq - q0);
+  if (threadIdx.x < SCAN_QPB) {
+    bd[threadIdx.x] = std::numeric_limits<float>::max();
+    bj[threadIdx.x] = 0u;
+  }
+  for (uint32_t t0 = 0; t0 < p.n_scan; t0 += p.scan_tile_rows) {
+    const uint32_t rows = min(p.scan_tile_rows, p.n_scan - t0);
+    __syncthreads();  // everyone is done with the previous tile
+    for (uint32_t c = threadIdx.x; c < rows * p.nchunks; c += SCAN_WAVES * WAVE) {
+      const uint32_t r = c / p.nchunks, k = c % p.nchunks;
+      *reinterpret_cast<uint4*>(tile + r * p.scan_tile_stride + k * 16u) =
+          *reinterpret_cast<const uint4*>(p.vectors + (uint64_t)(t0 + r) * p.scan_step * p.row_bytes + k * 16u);
+    }
+    __syncthreads();
+    for (uint32_t qq = wave; qq < nqb; qq += SCAN_WAVES) {
+      const T* qsrc = reinterpret_cast<const T*>(p.queries) + (uint64_t)(q0 + qq) * p.dim;
+      T* qdst = reinterpret_cast<T*>(qlds);
+      const int padded = (int)(qbytes / sizeof(T));
+      for (int i = lane; i < padded; i += WAVE) qdst[i] = i < (int)p.dim ? qsrc[i] : T(0);
+      wave_sync();
+      float best_d = std::numeric_limits<float>::max();
+      uint32_t best_j = 0;
+      scan_rows<T, METRIC, G, CU, FULL>(tile, p.scan_tile_stride, 1u, (int)p.nchunks, qlds, rows, t0, lane, best_d, best_j);
+      wave_argmin(best_d, best_j);
+      if (lane == 0 && best_d < bd[qq]) {  // later tiles hold larger indices: strict '<' keeps the first minimum
+        bd[qq] = best_d;
+        bj[qq] = best_j;
+      }
+      wave_sync();  // qlds is rewritten for the next query
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nqb) {
+    p.entry_node_out[q0 + threadIdx.x] = bj[threadIdx.x] * p.scan_step;
+    p.entry_dist_out[q0 + threadIdx.x] = bd[threadIdx.x];
+  }
+}
+
 template <typename T, int METRIC, int G, int CU, bool FULL>
 __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kernel(const SearchParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -608,42 +728,14 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
     PH_MARK(0);
 
     // ---- entry-point selection (Index.h:845-870): argmin over nodes 0, s, 2s, ... -----------
-    float best_d = std::numeric_limits<float>::max();
-    uint32_t best_j = 0;
-    {
-      constexpr int VPW = WAVE / G;
-      const int v = lane / G;
-      for (uint32_t j0 = 0; j0 < p.n_scan; j0 += VPW * PU) {
-        uint32_t sid[PU];
-        bool sval[PU];
-        float sd[PU];
-#pragma unroll
-        for (int pu = 0; pu < PU; pu++) {
-          const uint32_t j = j0 + pu * VPW + v;
-          sval[pu] = j < p.n_scan;
-          sid[pu] = j * p.scan_step;
-        }
-        const int npass = (int)min((uint32_t)PU, (p.n_scan - j0 + VPW - 1) / VPW);
-        batch_dists<T, METRIC, G, CU, FULL>(p, qlds, sid, sval, npass, sd, lane);
-#pragma unroll
-        for (int pu = 0; pu < PU; pu++) {
-          if (sval[pu] && sd[pu] < best_d) {  // strict '<': first minimum wins (Index.h:864)
-            best_d = sd[pu];
-            best_j = j0 + pu * VPW + v;
-          }
-        }
-      }
+    float best_d;
+    uint32_t entry;
+    if (p.entry_node) {  // K0 ran: entry point and its distance were computed for the whole batch
+      best_d = rfl(p.entry_dist[qi]);
+      entry = (uint32_t)rfl((int)p.entry_node[qi]);
+    } else {
+      entry = scan_entry_points<T, METRIC, G, CU, FULL>(p, qlds, lane, best_d);
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      float od = __shfl_xor(best_d, o, WAVE);
-      uint32_t oj = __shfl_xor(best_j, o, WAVE);
-      if (od < best_d || (od == best_d && oj < best_j)) {
-        best_d = od;
-        best_j = oj;
-      }
-    }
-    const uint32_t entry = best_j * p.scan_step;
     PH_MARK(1);
 
     // ---- beam search (Index.h:606-707) -------------------------------------------------------
@@ -727,7 +819,7 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
             cid[pu] = cval[pu] ? stage_ids[slot] : 0u;
           }
           const int npass = min(PU, (n - base + VPW - 1) / VPW);
-          batch_dists<T, METRIC, G, CU, FULL>(p, qlds, cid, cval, npass, cd, lane);
+          batch_dists<T, METRIC, G, CU, FULL>(p.vectors, p.row_bytes, (int)p.nchunks, qlds, cid, cval, npass, cd, lane);
           PH_MARK(5);
 
           // ---- admissions in link order (Index.h:667-705).  Superset filter first: max_dist never grows
@@ -978,6 +1070,31 @@ kernel_fn pick_cfg(int c) {
   }
 }
 
+template <typename T, int METRIC, bool FULL>
+kernel_fn pick_scan_cfg(int c) {
+  switch (c) {
+    case 0: return entry_scan_kernel<T, METRIC, 8, 1, FULL>;
+    case 1: return entry_scan_kernel<T, METRIC, 8, 2, FULL>;
+    case 2: return entry_scan_kernel<T, METRIC, 8, 4, FULL>;
+    case 3: return entry_scan_kernel<T, METRIC, 16, 4, FULL>;
+    case 4: return entry_scan_kernel<T, METRIC, 32, 4, FULL>;
+    default: return entry_scan_kernel<T, METRIC, 64, 4, FULL>;
+  }
+}
+
+template <typename T>
+kernel_fn pick_scan_metric(int metric, int cfg, bool full) {
+  if (metric == FNV_METRIC_L2)
+    return full ? pick_scan_cfg<T, FNV_METRIC_L2, true>(cfg) : pick_scan_cfg<T, FNV_METRIC_L2, false>(cfg);
+  return full ? pick_scan_cfg<T, FNV_METRIC_IP, true>(cfg) : pick_scan_cfg<T, FNV_METRIC_IP, false>(cfg);
+}
+
+kernel_fn pick_scan_kernel(int dtype, int metric, int cfg, bool full) {
+  if (dtype == FNV_DTYPE_FLOAT32) return pick_scan_metric<float>(metric, cfg, full);
+  if (dtype == FNV_DTYPE_UINT8) return pick_scan_metric<uint8_t>(metric, cfg, full);
+  return pick_scan_metric<int8_t>(metric, cfg, full);
+}
+
 template <typename T>
 kernel_fn pick_metric(int metric, int cfg, bool full) {
   if (metric == FNV_METRIC_L2) return full ? pick_cfg<T, FNV_METRIC_L2, true>(cfg) : pick_cfg<T, FNV_METRIC_L2, false>(cfg);
@@ -1003,10 +1120,12 @@ struct fnv_index_s {
   int num_cus = 0;
   // options
   int64_t visited_factor = 27, visited_slots = 0, cand_factor = 2, cand_slots = 0, spill_entries = 16384,
-          blocks_per_cu = 0, visited_wide = 0;
+          blocks_per_cu = 0, visited_wide = 0, entry_kernel = 0;
   // workspace (grown on demand)
   uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status
   unsigned long long* d_phase = nullptr;  // profiling builds only
+  void* d_entry = nullptr;  // [nq] uint32 entry nodes | [nq] float entry distances (K0 output)
+  size_t entry_bytes = 0;
   uint32_t* d_bitmap = nullptr;
   size_t bitmap_bytes = 0;
   unsigned long long* d_spill = nullptr;
@@ -1188,7 +1307,7 @@ int fnv_index_free(fnv_index_t ix) {
   if (!ix) return FNV_OK;
   (void)hipSetDevice(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_bitmap, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase};
+  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_bitmap, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase, ix->d_entry};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (ix->ev0) (void)hipEventDestroy(ix->ev0);
@@ -1213,6 +1332,7 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   else if (n == "spill_entries") ix->spill_entries = std::max<int64_t>(1, value);
   else if (n == "blocks_per_cu") ix->blocks_per_cu = value;
   else if (n == "visited_wide") ix->visited_wide = value;
+  else if (n == "entry_kernel") ix->entry_kernel = value;
   else return fail(FNV_ERR_INVALID, "unknown option: " + n);
   return FNV_OK;
 }
@@ -1364,6 +1484,29 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
 
   HIP_TRY(hipMemsetAsync(ix->d_dispenser, 0, 2 * sizeof(uint32_t), stream));
   HIP_TRY(hipEventRecord(ix->ev0, stream));
+  if (ix->entry_kernel) {
+    // K0: one pass over the shared entry-scan nodes for the whole batch (LDS-staged), same stream
+    const size_t need_entry = (size_t)nq * 8;
+    if (need_entry > ix->entry_bytes) {
+      if (ix->d_entry) HIP_TRY(hipFree(ix->d_entry));
+      ix->d_entry = nullptr;
+      ix->entry_bytes = 0;
+      HIP_TRY(hipMalloc(&ix->d_entry, need_entry));
+      ix->entry_bytes = need_entry;
+    }
+    p.entry_node_out = (uint32_t*)ix->d_entry;
+    p.entry_dist_out = (float*)((uint8_t*)ix->d_entry + (size_t)nq * 4);
+    p.scan_tile_stride = p.row_bytes + 16;
+    const uint32_t fixed = SCAN_WAVES * p.q_chunks * 16 + SCAN_QPB * 8;
+    p.scan_tile_rows = std::max<uint32_t>(1, std::min<uint32_t>(p.n_scan, (64u * 1024u) / p.scan_tile_stride));
+    const uint32_t scan_lds = fixed + p.scan_tile_rows * p.scan_tile_stride;
+    kernel_fn scan = pick_scan_kernel(ix->dtype, ix->metric, cfg, full);
+    HIP_TRY(hipFuncSetAttribute((const void*)scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
+    hipLaunchKernelGGL(scan, dim3((unsigned)((nq + SCAN_QPB - 1) / SCAN_QPB)), dim3(SCAN_WAVES * WAVE), scan_lds, stream, p);
+    HIP_TRY(hipGetLastError());
+    p.entry_node = p.entry_node_out;
+    p.entry_dist = p.entry_dist_out;
+  }
   hipLaunchKernelGGL(kern, dim3(nslots), dim3(WAVE), lds_bytes, stream, p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ix->ev1, stream));

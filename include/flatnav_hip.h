@@ -101,6 +101,9 @@ int fnv_index_free(fnv_index_t index);
  *   "cand_slots"      force the LDS candidate-heap capacity (0 = from factor)
  *   "spill_entries"   per-slot HBM spill capacity of the candidate heap (default 16384)
  *   "blocks_per_cu"   cap resident query slots per CU (0 = occupancy limit)
+ *   "entry_kernel"    1 = entry points of the whole batch come from the LDS-staged entry_scan_kernel (K0);
+ *                     0 (default) = every query scans them inside the search kernel.  Same results bit for
+ *                     bit; measured equally fast on MI355X (the shared scan rows are L2 hits either way)
  *   "visited_wide"    1 = always use the 32-bit open-addressing visited table (default 0: the 16-bit-tag
  *                     bucketed table whenever node-id width allows it) */
 int fnv_set_option(fnv_index_t index, const char* name, int64_t value);

@@ -201,3 +201,21 @@ def test_beam_too_large_for_lds_is_an_error(oracle_mod, hipmod):
     dev = _upload(hipmod, ix)
     with pytest.raises(ValueError):
         dev.search(Q, 10, 20000)
+
+
+@pytest.mark.parametrize("dim,dt,metric", [(128, "float32", "l2"), (768, "float32", "ip"), (100, "float32", "ip"),
+                                           (64, "uint8", "l2")])
+def test_entry_scan_kernel_matches_in_kernel_scan(oracle_mod, hipmod, dim, dt, metric):
+    # K0 (batched, LDS-staged entry-point selection; several LDS tiles at d=768) vs the in-kernel scan
+    rng = np.random.default_rng(dim)
+    n = 5000
+    X = rng.integers(0, 16 if metric == "ip" else 256, (n, dim)).astype(dt)
+    Q = rng.integers(0, 16 if metric == "ip" else 256, (333, dim)).astype(dt)
+    ix = _build(oracle_mod, metric, dt, X, 16, efc=64)
+    dev = _upload(hipmod, ix)
+    for n_init in (100, 7, 1000, 5000):
+        o = ix.search(Q, 10, 64, n_init, stats=True)
+        dev.set_option("entry_kernel", 1)
+        _assert_exact(o, dev.search(Q, 10, 64, n_init, stats=True))
+        dev.set_option("entry_kernel", 0)
+        _assert_exact(o, dev.search(Q, 10, 64, n_init, stats=True))
