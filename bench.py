@@ -44,9 +44,10 @@ def recorded_traffic(n, nq, ef):
         rec = json.load(open(path))
     except (OSError, ValueError):
         return None
-    if (rec.get("n"), rec.get("nq"), rec.get("ef")) != (n, nq, ef):
-        return None
-    return rec.get("hbm_bytes_per_launch_corrected")
+    for r in rec if isinstance(rec, list) else [rec]:
+        if (r.get("n"), r.get("nq"), r.get("ef")) == (n, nq, ef):
+            return r.get("hbm_bytes_per_launch_corrected")
+    return None
 
 
 def main() -> None:
@@ -262,8 +263,9 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "beam_search_kernel<%s, L2, G=8, CU=%d, FULL>" % ("float" if DT == "float32" else "uint8_t",
-                                                                              4 if DT == "float32" else 1),
+                # name as rocprofv3 prints it: <element type, metric 0=L2, G lanes per vector, CU loads, FULL rows>
+                "kernel": "beam_search_kernel<%s, 0, 8, %d, true>" % ("float" if DT == "float32" else "unsigned char",
+                                                                     4 if DT == "float32" else 1),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
