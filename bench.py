@@ -55,7 +55,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=1_000_000, help="index size")
+    ap.add_argument("--index-size", dest="n", type=int, default=1_000_000, help="number of indexed vectors")
     ap.add_argument("--nq", type=int, default=10_000, help="queries per batch per GPU")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--M", type=int, default=32)
@@ -81,12 +81,20 @@ def main() -> None:
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
                              % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    # BENCH_SHARE_GPU=1 (testing only): all ranks use cuda:0 and talk over gloo, so the multi-rank control flow
+    # can be exercised on a single-GPU box; the real multi-GPU run is one rank per GPU over RCCL.
+    share_gpu = os.environ.get("BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import flatnav_amd as flatnav
     from flatnav_amd import datasets as ds
