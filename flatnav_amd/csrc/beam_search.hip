@@ -106,6 +106,10 @@ struct LdsHeap {
     const uint4 c = *reinterpret_cast<const uint4*>(p + 2 * i + 1);
     return __uint_as_float(c.z) < __uint_as_float(c.x);
   }
+  // Predicated store without touching EXEC: lanes with cond == false write into the scratch word just
+  // below the array (p[-1]: the 8 bytes that pad the array to its 16n+8 start).  One VALU select instead of a
+  // scalar saveexec / branch / restore sequence -- the scalar unit is shared by every wave of the CU.
+  __device__ __forceinline__ void set_if(bool cond, int i, fnv_stl::Entry e) { p[cond ? i : -1] = pack(e); }
 };
 
 // Candidates heap: first `cap` entries in LDS, the rest in a per-slot HBM spill area (rare; the
@@ -120,6 +124,9 @@ struct CandHeap {
     else spill[i - cap] = pack(e);
   }
   __device__ __forceinline__ bool leftChildWins(int i) const { return get(2 * i + 2).key < get(2 * i + 1).key; }
+  __device__ __forceinline__ void set_if(bool cond, int i, fnv_stl::Entry e) {
+    if (cond) set(i, e);
+  }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -203,7 +210,7 @@ __device__ __forceinline__ void coop_push(H& h, int n, fnv_stl::Entry v, int lan
   const fnv_stl::Entry anc = h.get(max((int)(m1 >> sh) - 1, 0));
   const unsigned long long run = __ballot(lane < depth && anc.key < v.key);
   const int t = __ffsll((long long)~run) - 1;  // lanes >= depth vote false, so t <= depth
-  if (lane <= t) h.set((int)(m1 >> lane) - 1, lane < t ? anc : v);  // lanes < t: ancestor one level down; lane t: v
+  h.set_if(lane <= t, (int)(m1 >> lane) - 1, lane < t ? anc : v);  // lanes < t: ancestor one level down; lane t: v
   wave_sync();
   ph.mark(phbase);
 }
@@ -299,7 +306,7 @@ __device__ __forceinline__ void coop_pop(H& h, int n, int lane, PhaseTimer& ph, 
   }
   const unsigned long long fail = ~__ballot(back) & ((1ull << L) - 1ull);  // L <= 31
   const int jf = fail ? 63 - __clzll((long long)fail) : -1;  // deepest level whose move survives
-  if (lane <= jf + 1) h.set(my_p, lane <= jf ? val : v);
+  h.set_if(lane <= jf + 1, my_p, lane <= jf ? val : v);
   if (KEEP_TOP && lane == 0) h.set(len, top);  // std::pop_heap parks the old top in the vacated slot
   wave_sync();
   ph.mark(phbase + 2);
@@ -401,8 +408,10 @@ struct Dist<int8_t, METRIC> : DistInt<int8_t, METRIC> {};
 // ---------------------------------------------------------------------------------------------
 // Distances from the query (in LDS, zero padded to q_chunks) to one BATCH of up to PU * (64/G) nodes.
 // Lane layout: g = lane % G walks the 16-byte chunks of a row (chunk g, g+G, ...), v = lane / G picks the
-// vector of a pass; pass pu holds batch slot pu*(64/G) + v.  Inputs id[pu] / valid[pu] are per lane (equal
-// within a G-lane group); `npass` (wave-uniform) = number of passes that hold at least one vector.  All
+// vector of a pass; pass pu holds batch slot pu*(64/G) + v.  id[pu] is per lane (equal within a G-lane group) and
+// must be a legal row for EVERY lane of passes < npass: callers give lanes beyond the last real slot the id of
+// the last real one, whose loads coalesce with the real ones (no extra traffic, no EXEC juggling); their
+// results are simply ignored.  `npass` (wave-uniform) = number of passes that hold at least one vector.  All
 // PU*CU loads of an inner iteration are issued before the first use.  Results stay in registers: every
 // lane of a group ends with the group's distance in out[pu].
 // ---------------------------------------------------------------------------------------------
@@ -410,8 +419,7 @@ struct Dist<int8_t, METRIC> : DistInt<int8_t, METRIC> {};
 // entry-scan kernel (same arithmetic and summation order in both, so their distances agree bit for bit).
 template <typename T, int METRIC, int G, int CU, bool FULL>
 __device__ __forceinline__ void batch_dists(const uint8_t* rows, uint32_t row_stride, int nchunks, const uint4* qlds,
-                                            const uint32_t (&id)[PU], const bool (&valid)[PU], int npass,
-                                            float (&out)[PU], int lane) {
+                                            const uint32_t (&id)[PU], int npass, float (&out)[PU], int lane) {
   typedef Dist<T, METRIC> D;
   typedef typename D::acc_t acc_t;
   const int g = lane % G;
@@ -419,7 +427,7 @@ __device__ __forceinline__ void batch_dists(const uint8_t* rows, uint32_t row_st
   const uint8_t* rowp[PU];
 #pragma unroll
   for (int pu = 0; pu < PU; pu++) {
-    rowp[pu] = rows + (uint64_t)(valid[pu] ? id[pu] : 0u) * row_stride;
+    rowp[pu] = rows + (uint64_t)id[pu] * row_stride;
     acc[pu] = D::zero();
   }
   if (FULL) {
@@ -434,8 +442,7 @@ __device__ __forceinline__ void batch_dists(const uint8_t* rows, uint32_t row_st
         if (pu < npass) {  // wave-uniform: skip passes that hold no vector at all
 #pragma unroll
           for (int cu = 0; cu < CU; cu++)
-            y[pu][cu] = valid[pu] ? *reinterpret_cast<const uint4*>(rowp[pu] + (c0 + cu * G) * 16)
-                                  : make_uint4(0, 0, 0, 0);
+            y[pu][cu] = *reinterpret_cast<const uint4*>(rowp[pu] + (c0 + cu * G) * 16);
         }
       }
 #pragma unroll
@@ -456,8 +463,7 @@ __device__ __forceinline__ void batch_dists(const uint8_t* rows, uint32_t row_st
         for (int cu = 0; cu < CU; cu++) {
           const int c = c0 + cu * G + g;
           const int cc = c < nchunks ? c : nchunks - 1;  // clamp: always a legal address
-          y[pu][cu] = valid[pu] ? *reinterpret_cast<const uint4*>(rowp[pu] + (uint32_t)cc * 16u)
-                                : make_uint4(0, 0, 0, 0);
+          y[pu][cu] = *reinterpret_cast<const uint4*>(rowp[pu] + (uint32_t)cc * 16u);
         }
       }
     }
@@ -594,10 +600,10 @@ __device__ __forceinline__ void scan_rows(const uint8_t* rows, uint32_t stride_r
     for (int pu = 0; pu < PU; pu++) {
       const uint32_t j = j0 + pu * VPW + v;
       sval[pu] = j < count;
-      sid[pu] = j * id_mul;
+      sid[pu] = min(j, count - 1) * id_mul;
     }
     const int npass = (int)min((uint32_t)PU, (count - j0 + VPW - 1) / VPW);
-    batch_dists<T, METRIC, G, CU, FULL>(rows, stride_rows, nchunks, qlds, sid, sval, npass, sd, lane);
+    batch_dists<T, METRIC, G, CU, FULL>(rows, stride_rows, nchunks, qlds, sid, npass, sd, lane);
 #pragma unroll
     for (int pu = 0; pu < PU; pu++) {
       if (sval[pu] && sd[pu] < best_d) {  // strict '<': first minimum wins (Index.h:864)
@@ -797,7 +803,7 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
         ovf = __ballot(ovf) != 0ull;  // wave-uniform
         const unsigned long long newmask = __ballot(isnew);
         const int n = __popcll(newmask);
-        if (isnew) stage_ids[__popcll(newmask & ((1ull << lane) - 1ull))] = id;  // keeps link order
+        stage_ids[isnew ? __popcll(newmask & ((1ull << lane) - 1ull)) : WAVE] = id;  // keeps link order; slot 64 = bin
         vis_count += n;
         wave_sync();
         PH_MARK(4);
@@ -816,10 +822,10 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
           for (int pu = 0; pu < PU; pu++) {
             const int slot = base + pu * VPW + v;
             cval[pu] = slot < n;
-            cid[pu] = cval[pu] ? stage_ids[slot] : 0u;
+            cid[pu] = stage_ids[min(slot, n - 1)];  // lanes past the end re-read the last real id
           }
           const int npass = min(PU, (n - base + VPW - 1) / VPW);
-          batch_dists<T, METRIC, G, CU, FULL>(p.vectors, p.row_bytes, (int)p.nchunks, qlds, cid, cval, npass, cd, lane);
+          batch_dists<T, METRIC, G, CU, FULL>(p.vectors, p.row_bytes, (int)p.nchunks, qlds, cid, npass, cd, lane);
           PH_MARK(5);
 
           // ---- admissions in link order (Index.h:667-705).  Superset filter first: max_dist never grows
@@ -1439,7 +1445,7 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
   p.off_vis = off;
   off = align16(off + p.vis_bytes);
   p.off_stage_ids = off;
-  off = align16(off + WAVE * 4);
+  off = align16(off + (WAVE + 1) * 4);  // + one write-only slot for lanes with nothing to stage
   p.off_stage_d = off;
   off = align16(off + WAVE * 4);
   p.off_ovf = off;
