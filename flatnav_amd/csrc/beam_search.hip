@@ -80,7 +80,7 @@ struct SearchParams {
   uint32_t vis_mult;       // tag16: buckets = vis_mult * 2^k with vis_mult in {1, 3}
   uint32_t off_ovf;        // LDS: [0] count, [1..OVF_LIST] ids that went to the HBM bitmap
   uint32_t cand_slots, spill_entries, bitmap_words;
-  uint32_t off_q, off_nbr, off_cand, off_vis, off_stage_ids, off_stage_d;
+  uint32_t off_q, off_nbr, off_cand, off_vis, off_stage_ids;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1446,8 +1446,6 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
   off = align16(off + p.vis_bytes);
   p.off_stage_ids = off;
   off = align16(off + (WAVE + 1) * 4);  // + one write-only slot for lanes with nothing to stage
-  p.off_stage_d = off;
-  off = align16(off + WAVE * 4);
   p.off_ovf = off;
   off = align16(off + (OVF_LIST + 2) * 4);
   const uint32_t lds_bytes = off;
