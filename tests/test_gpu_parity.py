@@ -219,3 +219,50 @@ def test_entry_scan_kernel_matches_in_kernel_scan(oracle_mod, hipmod, dim, dt, m
         _assert_exact(o, dev.search(Q, 10, 64, n_init, stats=True))
         dev.set_option("entry_kernel", 0)
         _assert_exact(o, dev.search(Q, 10, 64, n_init, stats=True))
+
+
+@pytest.mark.parametrize("dim,dt", [(1, "float32"), (3, "uint8"), (5, "int8"), (33, "float32")])
+def test_tiny_and_ragged_rows(oracle_mod, hipmod, dim, dt):
+    # rows shorter than / not a multiple of one 16-byte chunk: zero padding must not change distances
+    rng = np.random.default_rng(dim)
+    lo, hi = (-20, 20) if dt == "int8" else (0, 40)
+    X = rng.integers(lo, hi, (700, dim)).astype(dt)
+    Q = rng.integers(lo, hi, (90, dim)).astype(dt)
+    for metric in ("l2", "ip"):
+        ix = _build(oracle_mod, metric, dt, X, 8, efc=40)
+        dev = _upload(hipmod, ix)
+        _assert_exact(ix.search(Q, 5, 30, stats=True), dev.search(Q, 5, 30, stats=True))
+
+
+def test_degenerate_sizes(oracle_mod, hipmod):
+    rng = np.random.default_rng(9)
+    X = rng.integers(0, 9, (3, 6)).astype(np.float32)
+    for n in (1, 2, 3):  # single node: every link is a self-loop
+        ix = oracle_mod.OracleIndex.create("l2", 6, 3, 4)
+        ix.add(X[:n], 10)
+        dev = _upload(hipmod, ix)
+        _assert_exact(ix.search(X, 2, 5, stats=True), dev.search(X, 2, 5, stats=True))
+        _assert_exact(ix.search(X, 1, 1, 1, stats=True), dev.search(X, 1, 1, 1, stats=True))
+    # empty batch: nothing to do, nothing written
+    d, l = dev.search(np.zeros((0, 6), dtype=np.float32), 3, 10)
+    assert d.shape == (0, 3) and l.shape == (0, 3)
+    # one query, host path and device path agree
+    import torch
+
+    q = torch.from_numpy(X[:1]).cuda()
+    dd = torch.empty((1, 2), dtype=torch.float32, device="cuda")
+    dl = torch.empty((1, 2), dtype=torch.int32, device="cuda")
+    dev.search_device(q.data_ptr(), 1, 2, 5, 100, dd.data_ptr(), dl.data_ptr())
+    torch.cuda.synchronize()
+    dev.status()
+    hd, hl = dev.search(X[:1], 2, 5)
+    assert np.array_equal(dd.cpu().numpy(), hd) and np.array_equal(dl.cpu().numpy(), hl)
+
+
+def test_many_queries_more_than_slots(oracle_mod, hipmod):
+    # 20 000 queries over ~3 000 resident slots: the dispenser hands every query out exactly once
+    X, Q = ds.sift_like(5000, 20000)
+    ix = _build(oracle_mod, "l2", "float32", X, 16, efc=64)
+    dev = _upload(hipmod, ix)
+    o = ix.search(Q, 10, 40, threads=8, stats=True)
+    _assert_exact(o, dev.search(Q, 10, 40, stats=True))
