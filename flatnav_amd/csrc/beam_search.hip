@@ -38,12 +38,14 @@ namespace {
 
 constexpr uint32_t EMPTY_ID = 0xFFFFFFFFu;
 constexpr int WAVE = 64;
+// Passes (vectors per lane group) whose loads are in flight together.  3 keeps the kernel at 124-128 VGPRs = 4 waves
+// per SIMD (16 per CU); 4 needs 148 VGPRs (12 per CU) and measured 2-14 % slower on every configuration tried.
 #ifndef FNV_PU
-#define FNV_PU 4
+#define FNV_PU 3
 #endif
 constexpr int PU = FNV_PU;  // vector "passes" whose loads are issued back to back before any use
 #ifndef FNV_MIN_WAVES_PER_SIMD
-#define FNV_MIN_WAVES_PER_SIMD 3  // __launch_bounds__ 2nd argument: register budget 512/3 per lane
+#define FNV_MIN_WAVES_PER_SIMD 4  // __launch_bounds__ 2nd argument: register budget 512/4 = 128 per lane
 #endif
 
 enum : int { ST_OK = 0, ST_CAND_OVERFLOW = 1 };
