@@ -13,8 +13,8 @@
 // Execution model: one 64-lane wavefront = one query at a time; a
 // persistent grid of query slots (as many as LDS lets stay resident) pulls query ids
 // from an atomic dispenser.  Per query, in LDS: the query vector, the two binary
-// heaps of the reference (moved with libstdc++'s exact algorithm, stl_exact.h), an
-// exact open-addressing visited set, and a 64-entry staging area.  Per hop the wave
+// heaps of the reference (moved with libstdc++'s exact algorithm, flatnav/util/StlExact.h,
+// cooperatively by the 64 lanes), an exact 16-bit-tag visited set, and a 64-entry id staging area.  Per hop the wave
 // loads one link row (M ids, coalesced), tests/marks all of them in the visited set
 // in parallel, gathers the unvisited neighbours' vectors with 16-byte loads (G lanes
 // per vector so each lane group reads whole 128-byte lines, PU*CU loads in flight per
@@ -544,37 +544,55 @@ __device__ __forceinline__ void tag16_slot(const SearchParams& p, uint32_t h, ui
   tag = (rem << 1) + 1u + which;
 }
 
-__device__ __forceinline__ bool visited_insert_tag16(uint32_t* tab, const SearchParams& p, uint32_t id,
+// Called by ALL lanes (inactive ones pass act = false).  The probe is straight-line arithmetic (bitwise, no
+// short-circuit branches) inside a wave-uniform retry loop that normally runs once, so EXEC is only touched
+// around the CAS itself -- the scalar unit that manipulates EXEC is shared by every wave of the CU.
+__device__ __forceinline__ bool visited_insert_tag16(uint32_t* tab, const SearchParams& p, bool act, uint32_t id,
                                                      uint32_t* bitmap, uint32_t* ovf_list, bool& used_bitmap) {
   uint32_t b1, b2, t1, t2;
   tag16_slot(p, (id * 0x9E3779B1u) & p.vis_nmask, 0u, b1, t1);
   tag16_slot(p, (id * 0x85EBCA6Bu) & p.vis_nmask, 1u, b2, t2);
-  while (true) {
+  const uint32_t t1x = t1 | (t1 << 16), t2x = t2 | (t2 << 16);  // the tag in both halves of a word
+  uint32_t pending = act ? 1u : 0u, isnew = 0u;
+  while (__ballot(pending != 0u) != 0ull) {
     const uint2 B1 = *reinterpret_cast<const uint2*>(tab + 2 * b1);
     const uint2 B2 = *reinterpret_cast<const uint2*>(tab + 2 * b2);
-    if (has_tag(B1.x, t1) || has_tag(B1.y, t1) || has_tag(B2.x, t2) || has_tag(B2.y, t2)) return false;
-    const int e1 = zero_halves(B1.x) + zero_halves(B1.y), e2 = zero_halves(B2.x) + zero_halves(B2.y);
-    if (e1 == 0 && e2 == 0) {
-      const uint32_t bit = 1u << (id & 31);
-      const uint32_t old = atomicOr(&bitmap[id >> 5], bit);
-      used_bitmap = true;
-      if (!(old & bit)) {
-        const uint32_t pos = atomicAdd(&ovf_list[0], 1u);
-        if (pos < OVF_LIST) ovf_list[1 + pos] = id;
-        return true;
-      }
-      return false;
-    }
-    const bool first = e1 >= e2;
-    const uint2 B = first ? B1 : B2;
+    // zero16(w): bit 15 / 31 set iff the low / high half of w is zero (exact "has-zero-halfword" test)
+#define FNV_ZERO16(w) ((~(((w) & 0x7FFF7FFFu) + 0x7FFF7FFFu) & ~(w)) & 0x80008000u)
+    const uint32_t hit = FNV_ZERO16(B1.x ^ t1x) | FNV_ZERO16(B1.y ^ t1x) | FNV_ZERO16(B2.x ^ t2x) | FNV_ZERO16(B2.y ^ t2x);
+    const uint32_t z1x = FNV_ZERO16(B1.x), z1y = FNV_ZERO16(B1.y), z2x = FNV_ZERO16(B2.x), z2y = FNV_ZERO16(B2.y);
+#undef FNV_ZERO16
+    const int e1 = __popc(z1x) + __popc(z1y), e2 = __popc(z2x) + __popc(z2y);
+    const uint32_t found = hit != 0u ? 1u : 0u;
+    const uint32_t full = (e1 | e2) == 0 ? 1u : 0u;
+    const bool first = e1 >= e2;  // insert into the emptier bucket
+    const uint32_t zx = first ? z1x : z2x;
+    const uint32_t Bx = first ? B1.x : B2.x, By = first ? B1.y : B2.y;
     const uint32_t tag = first ? t1 : t2;
-    uint32_t* base = tab + 2 * (first ? b1 : b2);
-    const bool in_x = zero_halves(B.x) > 0;
-    const uint32_t oldw = in_x ? B.x : B.y;
+    const bool in_x = zx != 0u;
+    const uint32_t oldw = in_x ? Bx : By;
     const uint32_t neww = oldw | ((oldw & 0xFFFFu) == 0u ? tag : tag << 16);
-    if (atomicCAS(base + (in_x ? 0 : 1), oldw, neww) == oldw) return true;
-    // lost a race for that word: look again
+    const uint32_t try_cas = pending & (found ^ 1u) & (full ^ 1u);
+    uint32_t got = ~oldw;
+    if (try_cas) got = atomicCAS(tab + 2 * (first ? b1 : b2) + (in_x ? 0 : 1), oldw, neww);
+    const uint32_t won = try_cas & (got == oldw ? 1u : 0u);
+    isnew |= won;
+    const uint32_t to_bitmap = pending & (found ^ 1u) & full;  // both buckets full: the HBM bitmap decides (rare)
+    if (__ballot(to_bitmap != 0u) != 0ull) {
+      if (to_bitmap) {
+        const uint32_t bit = 1u << (id & 31);
+        const uint32_t old = atomicOr(&bitmap[id >> 5], bit);
+        used_bitmap = true;
+        if (!(old & bit)) {
+          const uint32_t pos = atomicAdd(&ovf_list[0], 1u);
+          if (pos < OVF_LIST) ovf_list[1 + pos] = id;
+          isnew = 1u;
+        }
+      }
+    }
+    pending = try_cas & (won ^ 1u);  // lost a race for that word: look again
   }
+  return isnew != 0u;
 }
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -756,9 +774,9 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
     uint32_t vis_count = 1;
     bool ovf = false;       // 32-bit table: switched to the bitmap; tag16: some id went to the bitmap
     if (lane == 0) {
-      if (p.vis_tag16) visited_insert_tag16(vis, p, entry, bitmap, ovf_list, ovf);
-      else visited_insert_lds(vis, vis_mask, p.vis_shift, entry);
+      if (!p.vis_tag16) visited_insert_lds(vis, vis_mask, p.vis_shift, entry);
     }
+    if (p.vis_tag16) visited_insert_tag16(vis, p, lane == 0, entry, bitmap, ovf_list, ovf);
     ovf = __ballot(ovf) != 0ull;
     int err = ST_OK;
     uint32_t n_dist = 0, n_hops = 0;
@@ -791,10 +809,10 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
         if (m0 > 0) id = act ? p.links[(uint64_t)(uint32_t)node * p.M + m0 + lane] : EMPTY_ID;
         PH_MARK(3);
         bool isnew = false;
-        if (act) {
-          if (p.vis_tag16) {
-            isnew = visited_insert_tag16(vis, p, id, bitmap, ovf_list, ovf);
-          } else if (!ovf) {
+        if (p.vis_tag16) {
+          isnew = visited_insert_tag16(vis, p, act, id, bitmap, ovf_list, ovf);
+        } else if (act) {
+          if (!ovf) {
             isnew = visited_insert_lds(vis, vis_mask, p.vis_shift, id);
           } else if (!visited_lookup_lds(vis, vis_mask, p.vis_shift, id)) {
             uint32_t bit = 1u << (id & 31);
