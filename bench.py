@@ -62,7 +62,7 @@ def main() -> None:
     ap.add_argument("--efc", type=int, default=100)
     ap.add_argument("--ef", type=int, default=0,
                     help="ef_search; 0 = the metric's rule: smallest ef of --ef-sweep with recall@10 >= 0.95")
-    ap.add_argument("--ef-sweep", default="50,60,75,100,150,200,400")
+    ap.add_argument("--ef-sweep", default="50,52,54,56,58,60,64,70,80,100,150,200,400")
     ap.add_argument("--K", type=int, default=10)
     ap.add_argument("--build-threads", type=int, default=0)
     ap.add_argument("--dtype", default="float32", choices=["float32", "uint8"],

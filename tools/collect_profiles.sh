@@ -12,7 +12,7 @@ EF=$(python3 -c "import json;print(json.load(open('$O/bench.json'))['config']['e
 echo "selected ef=$EF"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python3 $R/bench.py --no-cpu-baseline --steps 5 --ef $EF > $O/trace.log 2>&1
-for ef in 50 60; do
+for ef in $(echo 50 60 $EF | tr ' ' '\n' | sort -un); do
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_ef$ef -o bench -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 --ef $ef > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_ef$ef -o bench -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 --ef $ef > /dev/null 2>&1
 done

@@ -24,7 +24,7 @@ def counters(d):
 
 
 traffic = []
-for ef in (50, 60):
+for ef in sorted({50, 60, bench["config"]["ef_search"]}):
     f, meta = counters("fetch_ef%d" % ef)
     w, _ = counters("write_ef%d" % ef)
     F, W = f["FETCH_SIZE"], w["WRITE_SIZE"]
