@@ -272,7 +272,7 @@ def main() -> None:
             "roofline": {
                 "bound": "hbm",
                 # name as rocprofv3 prints it: <element type, metric 0=L2, G lanes per vector, CU loads, FULL rows>
-                "kernel": "beam_search_kernel<%s, 0, 8, %d, true>" % ("float" if DT == "float32" else "unsigned char",
+                "kernel": "fnv_dev::beam_search_kernel<%s, 0, 8, %d, true>" % ("float" if DT == "float32" else "unsigned char",
                                                                      4 if DT == "float32" else 1),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,

@@ -13,7 +13,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libflatnav_hip.so")
 SOURCES = [os.path.join(CSRC, "beam_search.hip")]
-DEPS = SOURCES + [os.path.join(ROOT, "include", "flatnav", "util", "StlExact.h"), os.path.join(ROOT, "include", "flatnav_hip.h")]
+DEPS = SOURCES + [os.path.join(CSRC, f) for f in ("search_params.h", "heaps.hpp", "distance.hpp", "visited.hpp", "kernels.hpp")] + [
+    os.path.join(ROOT, "include", "flatnav", "util", "StlExact.h"), os.path.join(ROOT, "include", "flatnav_hip.h")]
 
 
 def hipcc() -> str:
@@ -35,7 +36,7 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str | Non
     if not force and out == LIB and not needs_build():
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")] + ["-D" + d for d in defines] + SOURCES + [
+           "-Wno-unused-function", "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include")] + ["-D" + d for d in defines] + SOURCES + [
                "-o", out]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

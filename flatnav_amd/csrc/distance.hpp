@@ -1,0 +1,185 @@
+// distance.hpp -- part of the gfx950 search engine (device code; included only by beam_search.hip).
+// Cross-lane reductions, per-chunk distance arithmetic and the batched gather/distance primitive.
+#pragma once
+#include "search_params.h"
+namespace fnv_dev {
+
+// ---------------------------------------------------------------------------------------------
+// Cross-lane sums over aligned groups of G lanes (DPP inside a 16-lane row, bpermute above).
+// Every step adds the same two operands in both partner lanes, so all lanes of a group end with
+// bit-identical sums.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) {
+  return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
+}
+template <int G, typename A>
+__device__ __forceinline__ A group_sum(A v) {
+  v += dpp_mov<0xB1>(v);                       // quad_perm [1,0,3,2]  (lane ^ 1)
+  v += dpp_mov<0x4E>(v);                       // quad_perm [2,3,0,1]  (lane ^ 2)
+  if (G >= 8) v += dpp_mov<0x141>(v);          // row_half_mirror      (i <-> 7-i)
+  if (G >= 16) v += dpp_mov<0x140>(v);         // row_mirror           (i <-> 15-i)
+  if (G >= 32) v += __shfl_xor(v, 16, WAVE);
+  if (G >= 64) v += __shfl_xor(v, 32, WAVE);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Distance kernels on one 16-byte chunk pair.  L2 = sum (x-y)^2, IP = 1 - sum x*y
+// (L2DistanceDispatcher.h:10-17, IPDistanceDispatcher.h:10-16).  Integer element types
+// accumulate exactly in int32 (the reference's float/int32 accumulations agree with that while
+// the sum stays below 2^24).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int METRIC>
+struct Dist;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int METRIC>
+struct Dist<float, METRIC> {
+  // two partial sums per lane so subtract and multiply-add issue as packed f32 (v_pk_add_f32 / v_pk_fma_f32)
+  typedef f32x2 acc_t;
+  static __device__ __forceinline__ f32x2 zero() { return f32x2{0.f, 0.f}; }
+  static __device__ __forceinline__ f32x2 chunk(f32x2 acc, const uint4& x, const uint4& y) {
+    const f32x2 x0 = {__uint_as_float(x.x), __uint_as_float(x.y)}, x1 = {__uint_as_float(x.z), __uint_as_float(x.w)};
+    const f32x2 y0 = {__uint_as_float(y.x), __uint_as_float(y.y)}, y1 = {__uint_as_float(y.z), __uint_as_float(y.w)};
+    if (METRIC == FNV_METRIC_L2) {
+      const f32x2 t0 = x0 - y0, t1 = x1 - y1;
+      acc = __builtin_elementwise_fma(t0, t0, acc);
+      acc = __builtin_elementwise_fma(t1, t1, acc);
+    } else {
+      acc = __builtin_elementwise_fma(x0, y0, acc);
+      acc = __builtin_elementwise_fma(x1, y1, acc);
+    }
+    return acc;
+  }
+  static __device__ __forceinline__ float lane_sum(f32x2 a) { return a.x + a.y; }
+  static __device__ __forceinline__ float finish(float s) { return METRIC == FNV_METRIC_L2 ? s : 1.0f - s; }
+};
+
+template <typename T, int METRIC>
+struct DistInt {
+  typedef int acc_t;
+  static __device__ __forceinline__ int zero() { return 0; }
+  static __device__ __forceinline__ int lane_sum(int a) { return a; }
+  static __device__ __forceinline__ int elem(uint32_t w, int k) {
+    if (sizeof(T) == 1 && T(-1) < T(0)) return (int)(int8_t)(w >> (8 * k));
+    return (int)((w >> (8 * k)) & 0xffu);
+  }
+  static __device__ __forceinline__ int chunk(int acc, const uint4& x, const uint4& y) {
+    const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+    const uint32_t ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        int a = elem(xs[i], k), b = elem(ys[i], k);
+        if (METRIC == FNV_METRIC_L2) {
+          int t = a - b;
+          acc += t * t;
+        } else {
+          acc += a * b;
+        }
+      }
+    }
+    return acc;
+  }
+  static __device__ __forceinline__ float finish(int s) {
+    return METRIC == FNV_METRIC_L2 ? (float)s : 1.0f - (float)s;
+  }
+};
+template <int METRIC>
+struct Dist<uint8_t, METRIC> : DistInt<uint8_t, METRIC> {};
+template <int METRIC>
+struct Dist<int8_t, METRIC> : DistInt<int8_t, METRIC> {};
+
+// ---------------------------------------------------------------------------------------------
+// Distances from the query (in LDS, zero padded to q_chunks) to one BATCH of up to PU * (64/G) nodes.
+// Lane layout: g = lane % G walks the 16-byte chunks of a row (chunk g, g+G, ...), v = lane / G picks the
+// vector of a pass; pass pu holds batch slot pu*(64/G) + v.  id[pu] is per lane (equal within a G-lane group) and
+// must be a legal row for EVERY lane of passes < npass: callers give lanes beyond the last real slot the id of
+// the last real one, whose loads coalesce with the real ones (no extra traffic, no EXEC juggling); their
+// results are simply ignored.  `npass` (wave-uniform) = number of passes that hold at least one vector.  All
+// PU*CU loads of an inner iteration are issued before the first use.  Results stay in registers: every
+// lane of a group ends with the group's distance in out[pu].
+// ---------------------------------------------------------------------------------------------
+// Rows are addressed as rows + id * row_stride: the HBM vector table in the search kernel, an LDS tile in the
+// entry-scan kernel (same arithmetic and summation order in both, so their distances agree bit for bit).
+template <typename T, int METRIC, int G, int CU, bool FULL>
+__device__ __forceinline__ void batch_dists(const uint8_t* rows, uint32_t row_stride, int nchunks, const uint4* qlds,
+                                            const uint32_t (&id)[PU], int npass, float (&out)[PU], int lane) {
+  typedef Dist<T, METRIC> D;
+  typedef typename D::acc_t acc_t;
+  const int g = lane % G;
+  acc_t acc[PU];
+  const uint8_t* rowp[PU];
+#pragma unroll
+  for (int pu = 0; pu < PU; pu++) {
+    rowp[pu] = rows + (uint64_t)id[pu] * row_stride;
+    acc[pu] = D::zero();
+  }
+  if (FULL) {
+    // rows are a whole number of G*CU-chunk spans (e.g. d=128 f32: 32 chunks = 8 lanes x 4): no clamping, no
+    // tail select; one address per pass, the CU loads use immediate offsets
+#pragma unroll
+    for (int pu = 0; pu < PU; pu++) rowp[pu] += g * 16;
+    for (int c0 = 0; c0 < nchunks; c0 += G * CU) {
+      uint4 y[PU][CU];
+#pragma unroll
+      for (int pu = 0; pu < PU; pu++) {
+        if (pu < npass) {  // wave-uniform: skip passes that hold no vector at all
+#pragma unroll
+          for (int cu = 0; cu < CU; cu++)
+            y[pu][cu] = *reinterpret_cast<const uint4*>(rowp[pu] + (c0 + cu * G) * 16);
+        }
+      }
+#pragma unroll
+      for (int cu = 0; cu < CU; cu++) {
+        const uint4 x = qlds[c0 + cu * G + g];
+#pragma unroll
+        for (int pu = 0; pu < PU; pu++)
+          if (pu < npass) acc[pu] = D::chunk(acc[pu], x, y[pu][cu]);
+      }
+    }
+  } else {
+  for (int c0 = 0; c0 < nchunks; c0 += G * CU) {
+    uint4 y[PU][CU];
+#pragma unroll
+    for (int pu = 0; pu < PU; pu++) {
+      if (pu < npass) {  // wave-uniform: skip passes that hold no vector at all
+#pragma unroll
+        for (int cu = 0; cu < CU; cu++) {
+          const int c = c0 + cu * G + g;
+          const int cc = c < nchunks ? c : nchunks - 1;  // clamp: always a legal address
+          y[pu][cu] = *reinterpret_cast<const uint4*>(rowp[pu] + (uint32_t)cc * 16u);
+        }
+      }
+    }
+#pragma unroll
+    for (int cu = 0; cu < CU; cu++) {
+      const int c = c0 + cu * G + g;
+      const uint4 x = qlds[c];  // zero beyond the row (q_chunks covers the last c0 block)
+      const bool in_row = c < nchunks;
+#pragma unroll
+      for (int pu = 0; pu < PU; pu++) {
+        if (pu < npass) {
+          uint4 yy = y[pu][cu];
+          if (!in_row) yy = x;  // x is zero there: (0-0)^2 = 0 and 0*0 = 0
+          acc[pu] = D::chunk(acc[pu], x, yy);
+        }
+      }
+    }
+  }
+  }
+#pragma unroll
+  for (int pu = 0; pu < PU; pu++) {
+    out[pu] = 0.f;
+    if (pu < npass) out[pu] = D::finish(group_sum<G>(D::lane_sum(acc[pu])));
+  }
+}
+
+}  // namespace fnv_dev

@@ -1,0 +1,117 @@
+// visited.hpp -- part of the gfx950 search engine (device code; included only by beam_search.hip).
+// Exact visited sets in LDS (32-bit open addressing and the 16-bit-tag bucketed table).
+#pragma once
+#include "search_params.h"
+namespace fnv_dev {
+
+// ---------------------------------------------------------------------------------------------
+// Exact visited set: open addressing (linear probing) over uint32 ids in LDS, filled to at most
+// 3/4; once it would exceed that, the remaining insertions of the query go to a per-slot HBM
+// bitmap (one bit per node) that the slot clears again before its next query.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool visited_insert_lds(uint32_t* tab, uint32_t slots_mask, uint32_t shift, uint32_t id) {
+  uint32_t h = (id * 0x9E3779B1u) >> shift;
+  while (true) {
+    uint32_t cur = tab[h];
+    if (cur == id) return false;
+    if (cur == EMPTY_ID) {
+      uint32_t old = atomicCAS(&tab[h], EMPTY_ID, id);
+      if (old == EMPTY_ID) return true;
+      if (old == id) return false;
+    }
+    h = (h + 1) & slots_mask;
+  }
+}
+__device__ __forceinline__ bool visited_lookup_lds(const uint32_t* tab, uint32_t slots_mask, uint32_t shift,
+                                                   uint32_t id) {
+  uint32_t h = (id * 0x9E3779B1u) >> shift;
+  while (true) {
+    uint32_t cur = tab[h];
+    if (cur == id) return true;
+    if (cur == EMPTY_ID) return false;
+    h = (h + 1) & slots_mask;
+  }
+}
+
+// Exact visited set in 16 bits per element (used whenever the id width allows it).
+// ids < 2^nbits.  Two multiplicative hashes h_k(id) = (id * A_k) mod 2^nbits, A_k odd, are bijections
+// on nbits-bit integers, so (bucket = top bits of h_k, rem = remaining low bits, k) identifies the
+// id uniquely: the table stores only tag = ((rem << 1) | k) + 1 (0 = empty) -- no false positives.
+// A bucket is four 16-bit tags (8 bytes); an id may sit in either of its two buckets (inserted into
+// the emptier one).  If both buckets are full the id is recorded in the slot's HBM bitmap instead;
+// buckets never lose entries, so "both full -> ask the bitmap" stays consistent for the whole query.
+__device__ __forceinline__ bool has_tag(uint32_t w, uint32_t tag) {
+  return (w & 0xFFFFu) == tag || (w >> 16) == tag;
+}
+__device__ __forceinline__ int zero_halves(uint32_t w) { return ((w & 0xFFFFu) == 0u) + ((w >> 16) == 0u); }
+
+// Bucket geometry: buckets = mult * 2^k (mult 1 or 3, so tables of 2^j or 3*2^j slots exist), t = nbits - k.
+// x = h * mult; bucket = x >> t; the low t bits of x, divided by mult, number the ids inside the bucket.
+__device__ __forceinline__ void tag16_slot(const SearchParams& p, uint32_t h, uint32_t which, uint32_t& bucket,
+                                           uint32_t& tag) {
+  const uint32_t x = h * p.vis_mult;
+  bucket = x >> p.vis_rshift;
+  uint32_t rem = x & p.vis_rmask;
+  if (p.vis_mult == 3) rem = (rem * 43691u) >> 17;  // rem / 3, exact below 2^16
+  tag = (rem << 1) + 1u + which;
+}
+
+// Called by ALL lanes (inactive ones pass act = false).  The probe is straight-line arithmetic (bitwise, no
+// short-circuit branches) inside a wave-uniform retry loop that normally runs once, so EXEC is only touched
+// around the CAS itself -- the scalar unit that manipulates EXEC is shared by every wave of the CU.
+__device__ __forceinline__ bool visited_insert_tag16(uint32_t* tab, const SearchParams& p, bool act, uint32_t id,
+                                                     uint32_t* bitmap, uint32_t* ovf_list, bool& used_bitmap) {
+  uint32_t b1, b2, t1, t2;
+  tag16_slot(p, (id * 0x9E3779B1u) & p.vis_nmask, 0u, b1, t1);
+  tag16_slot(p, (id * 0x85EBCA6Bu) & p.vis_nmask, 1u, b2, t2);
+  const uint32_t t1x = t1 | (t1 << 16), t2x = t2 | (t2 << 16);  // the tag in both halves of a word
+  uint32_t pending = act ? 1u : 0u, isnew = 0u;
+  while (__ballot(pending != 0u) != 0ull) {
+    const uint2 B1 = *reinterpret_cast<const uint2*>(tab + 2 * b1);
+    const uint2 B2 = *reinterpret_cast<const uint2*>(tab + 2 * b2);
+    // zero16(w): bit 15 / 31 set iff the low / high half of w is zero (exact "has-zero-halfword" test)
+#define FNV_ZERO16(w) ((~(((w) & 0x7FFF7FFFu) + 0x7FFF7FFFu) & ~(w)) & 0x80008000u)
+    const uint32_t hit = FNV_ZERO16(B1.x ^ t1x) | FNV_ZERO16(B1.y ^ t1x) | FNV_ZERO16(B2.x ^ t2x) | FNV_ZERO16(B2.y ^ t2x);
+    const uint32_t z1x = FNV_ZERO16(B1.x), z1y = FNV_ZERO16(B1.y), z2x = FNV_ZERO16(B2.x), z2y = FNV_ZERO16(B2.y);
+#undef FNV_ZERO16
+    const int e1 = __popc(z1x) + __popc(z1y), e2 = __popc(z2x) + __popc(z2y);
+    const uint32_t found = hit != 0u ? 1u : 0u;
+    const uint32_t full = (e1 | e2) == 0 ? 1u : 0u;
+    const bool first = e1 >= e2;  // insert into the emptier bucket
+    const uint32_t zx = first ? z1x : z2x;
+    const uint32_t Bx = first ? B1.x : B2.x, By = first ? B1.y : B2.y;
+    const uint32_t tag = first ? t1 : t2;
+    const bool in_x = zx != 0u;
+    const uint32_t oldw = in_x ? Bx : By;
+    const uint32_t neww = oldw | ((oldw & 0xFFFFu) == 0u ? tag : tag << 16);
+    const uint32_t try_cas = pending & (found ^ 1u) & (full ^ 1u);
+    uint32_t got = ~oldw;
+    if (try_cas) got = atomicCAS(tab + 2 * (first ? b1 : b2) + (in_x ? 0 : 1), oldw, neww);
+    const uint32_t won = try_cas & (got == oldw ? 1u : 0u);
+    isnew |= won;
+    const uint32_t to_bitmap = pending & (found ^ 1u) & full;  // both buckets full: the HBM bitmap decides (rare)
+    if (__ballot(to_bitmap != 0u) != 0ull) {
+      if (to_bitmap) {
+        const uint32_t bit = 1u << (id & 31);
+        const uint32_t old = atomicOr(&bitmap[id >> 5], bit);
+        used_bitmap = true;
+        if (!(old & bit)) {
+          const uint32_t pos = atomicAdd(&ovf_list[0], 1u);
+          if (pos < OVF_LIST) ovf_list[1 + pos] = id;
+          isnew = 1u;
+        }
+      }
+    }
+    pending = try_cas & (won ^ 1u);  // lost a race for that word: look again
+  }
+  return isnew != 0u;
+}
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float rfl(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+// ---------------------------------------------------------------------------------------------
+// The search kernel.
+// ---------------------------------------------------------------------------------------------
+
+}  // namespace fnv_dev

@@ -38,6 +38,14 @@ def test_library_exports_every_declared_symbol(libpath):
     assert lib.fnv_last_error() is not None
 
 
+def test_library_exports_nothing_else(libpath):
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", libpath], capture_output=True, text=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l)
+    assert exported == _declared_symbols()  # kernels and helpers stay hidden (-fvisibility=hidden)
+
+
 def test_library_contains_gfx950_code_object(libpath):
     blob = open(libpath, "rb").read()
     assert b"gfx950" in blob and b"beam_search_kernel" in blob

@@ -8,7 +8,7 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-
                        "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
                        os.path.join(ROOT, "flatnav_amd/csrc/beam_search.hip"), "-o", out], stderr=subprocess.DEVNULL)
 s = open(out).read()
-name = "_ZN12_GLOBAL__N_118beam_search_kernelIfLi0ELi8ELi4ELb1EEEvNS_12SearchParamsE"
+name = "_ZN7fnv_dev18beam_search_kernelIfLi0ELi8ELi4ELb1EEEvNS_12SearchParamsE"
 i = s.find(name + ":"); j = s.find(".Lfunc_end", i)
 lines = s[i:j].splitlines()
 cur = "start"; counts = collections.OrderedDict(); kinds = collections.defaultdict(collections.Counter)
