@@ -148,7 +148,8 @@ struct fnv_index_s {
   hipStream_t last_stream = nullptr;
   bool launched = false;
   uint64_t geom[6] = {0, 0, 0, 0, 0, 0};
-  std::mutex mu;
+  std::mutex mu;       // launch configuration + workspace growth
+  std::mutex host_mu;  // the host-buffer entry point owns d_q / d_out / stream for the whole call
 };
 
 namespace {
@@ -549,6 +550,7 @@ int fnv_search_batch(fnv_index_t ix, const void* queries, uint64_t nq, int K, in
   if (K <= 0 || ef_search <= 0) return fail(FNV_ERR_INVALID, "K and ef_search must be positive");
   if (nq == 0) return FNV_OK;
   if (!queries || !out_dist || !out_labels) return fail(FNV_ERR_INVALID, "null buffer");
+  std::lock_guard<std::mutex> host_lock(ix->host_mu);  // concurrent callers share one staging area: serialise
   HIP_TRY(hipSetDevice(ix->device));
   const size_t qbytes = (size_t)nq * ix->dim * dtype_size(ix->dtype);
   // one output slab: dist | labels | count | ndist | nhops

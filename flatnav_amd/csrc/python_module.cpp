@@ -102,8 +102,13 @@ class PyIndex : public std::enable_shared_from_this<PyIndex<dist_t, kType>> {
     py::array_t<float> dist({nq, static_cast<py::ssize_t>(K)});
     py::array_t<int> labels({nq, static_cast<py::ssize_t>(K)});
     std::vector<int32_t> counts(static_cast<size_t>(nq));
-    _index->searchBatch(queries.data(), static_cast<uint64_t>(nq), K, ef_search, num_initializations, dist.mutable_data(),
-                        labels.mutable_data(), counts.data());
+    {
+      const element_t* qptr = queries.data();
+      float* dptr = dist.mutable_data();
+      int* lptr = labels.mutable_data();
+      py::gil_scoped_release release;  // the GPU works; other Python threads may run
+      _index->searchBatch(qptr, static_cast<uint64_t>(nq), K, ef_search, num_initializations, dptr, lptr, counts.data());
+    }
     for (py::ssize_t q = 0; q < nq; ++q)  // bindings.cpp:184-189
       if (counts[static_cast<size_t>(q)] != K)
         throw std::runtime_error("Search did not return the expected number of results. Expected " + std::to_string(K) +

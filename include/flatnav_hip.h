@@ -108,7 +108,11 @@ int fnv_index_free(fnv_index_t index);
  *                     bucketed table whenever node-id width allows it) */
 int fnv_set_option(fnv_index_t index, const char* name, int64_t value);
 
-/* Batched search, host buffers.  queries: [nq][dim] elements of the index data type, C-contiguous.
+/* Thread safety: fnv_search_batch may be called concurrently on one index (calls are serialised inside);
+ * fnv_search_batch_device shares one per-index workspace, so at most one such launch may be in flight per index
+ * (launches on the same stream are naturally ordered).  Different indexes are independent.
+ *
+ * Batched search, host buffers.  queries: [nq][dim] elements of the index data type, C-contiguous.
  * out_dist/out_labels: [nq][K].  Rows with fewer than K reachable results are padded with
  * (+inf, -1) and reported through out_count[q] (nullable) -- the reference's binding raises
  * RuntimeError in that case (bindings.cpp:184-189); the host wrapper does the same.

@@ -101,3 +101,26 @@ def test_incremental_add_refreshes_device_copy(flatnav, oracle_mod):
     o = oracle_mod.OracleIndex.from_blob("l2", "float32", 128, 4000, 4000, 16, np.asarray(index._raw_blob()))
     od, ol = o.search(Q, 5, 50)
     assert np.array_equal(l2, ol) and np.array_equal(d2, od)
+
+
+def test_concurrent_callers_on_one_index(flatnav, oracle_mod):
+    # Index.search is re-entrant in the reference (per-call visited set from a pool); here concurrent callers are
+    # serialised inside the C ABI and the binding releases the GIL while the GPU works.
+    import threading
+
+    X, Q = ds.sift_like(8000, 1200)
+    index = flatnav.index.create("l2", 128, 8000, 16)
+    index.set_num_threads(4)
+    index.add(X, 64)
+    want = index.search(Q, 10, 64)
+    got = [None] * 6
+
+    def work(i):
+        got[i] = index.search(Q[i * 200:(i + 1) * 200], 10, 64)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    for i in range(6):
+        assert np.array_equal(got[i][0], want[0][i * 200:(i + 1) * 200])
+        assert np.array_equal(got[i][1], want[1][i * 200:(i + 1) * 200])
