@@ -175,7 +175,7 @@ def test_argument_errors(oracle_mod, hipmod):
         hipmod.DeviceIndex.upload(bad, ix.node_size, ix.data_size, ix.M, 300, "float32", "l2", 12)
 
 
-@pytest.mark.parametrize("M", [48, 64, 80, 130])
+@pytest.mark.parametrize("M", [1, 2, 3, 48, 64, 80, 130])
 def test_wide_link_rows(oracle_mod, hipmod, M):
     # rows wider than one wavefront are expanded 64 links at a time, still in link order
     rng = np.random.default_rng(M)
