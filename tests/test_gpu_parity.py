@@ -105,6 +105,14 @@ def test_float_data_within_tolerance(oracle_mod, hipmod, metric):
     print("max relative distance deviation GPU vs oracle (%s): %.2e" % (metric, worst))
     gt = ds.exact_topk_l2(X, Q, 10) if metric == "l2" else ds.exact_topk_ip(X, Q, 10)
     assert abs(ds.recall_at_k(ol, gt) - ds.recall_at_k(gl, gt)) < 1e-3
+    # Same graph searched with the REFERENCE's own compiled AVX-512 / -ffast-math distance kernel (oracle/_ref, when it
+    # was built): the GPU must stay within the same tolerance of the reference's float arithmetic.
+    if ix.use_reference_distance(True):
+        rd, rl = ix.search(Q, 10, 100)
+        same_r = (rl == gl).all(axis=1)
+        assert same_r.mean() >= 0.99
+        assert np.allclose(rd[same_r], gd[same_r], rtol=1e-5, atol=1e-6)
+        print("ids identical to the reference-distance search on %.2f%% of queries" % (100 * same_r.mean()))
 
 
 def test_small_index_and_short_results(oracle_mod, hipmod):
