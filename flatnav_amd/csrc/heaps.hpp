@@ -136,6 +136,13 @@ __device__ __forceinline__ void coop_push(H& h, int n, fnv_stl::Entry v, int lan
   ph.mark(phbase);
 }
 
+// One step of the root-to-leaf walk in 1-based numbering: m <- 2*m + mask[bit].  Two scalar instructions
+// (bit test into SCC, add-with-carry); the compiler's own sequence is shift/and/shift/or on 64-bit operands.
+__device__ __forceinline__ uint32_t walk_step(uint32_t m, unsigned long long mask, uint32_t bit) {
+  asm("s_bitcmp1_b64 %1, %2\n\ts_addc_u32 %0, %0, %0" : "+s"(m) : "s"(mask), "s"(bit) : "scc");
+  return m;
+}
+
 // KEEP_TOP: also park the removed top in the vacated slot, as std::pop_heap does (only the result tail
 // needs that; the beam loop never looks at the slot again).
 template <bool KEEP_TOP, class H>
@@ -164,10 +171,7 @@ __device__ __forceinline__ void coop_pop(H& h, int n, int lane, PhaseTimer& ph, 
     const bool lw = h.leftChildWins(min(max(lane - 1, 0), max(two - 1, 0)));  // always a legal pair
     const unsigned long long rw = __ballot(lane >= 1 && lane <= two && !lw);
     ph.mark(phbase);
-    while (m <= two1) {
-      m = (m << 1) | (uint32_t)((rw >> m) & 1ull);
-      L++;
-    }
+    while (m <= two1) m = walk_step(m, rw, m);
   } else if (two <= 4 * WAVE) {
     // <= 256 two-child nodes (heaps of <= 514 entries): four scalar masks, indexed by 0-based number
     // four independent 16-byte reads per lane, issued together (indices clamped to a legal pair)
@@ -176,15 +180,12 @@ __device__ __forceinline__ void coop_pop(H& h, int n, int lane, PhaseTimer& ph, 
     const unsigned long long r0 = __ballot(lane < two && !w0), r1 = __ballot(WAVE + lane < two && !w1);
     const unsigned long long r2 = __ballot(2 * WAVE + lane < two && !w2), r3 = __ballot(3 * WAVE + lane < two && !w3);
     ph.mark(phbase);
-    while (m <= 64u) {  // nodes 0..63 (levels 0-5, two > 63 here): first mask only
-      m = (m << 1) | (uint32_t)((r0 >> (m - 1)) & 1ull);
-      L++;
-    }
+    const unsigned long long r0s = r0 << 1;  // node of 1-based number m at bit m (numbers 1..63)
+    while (m <= 63u) m = walk_step(m, r0s, m);  // levels 0-5: all of these nodes have two children here (two > 63)
     while (m <= two1) {
       const uint32_t i0 = m - 1, w = i0 >> 6;
-      const unsigned long long rw = w == 1 ? r1 : w == 2 ? r2 : r3;
-      m = (m << 1) | (uint32_t)((rw >> (i0 & 63)) & 1ull);
-      L++;
+      const unsigned long long rw = w == 0 ? r0 : w == 1 ? r1 : w == 2 ? r2 : r3;
+      m = walk_step(m, rw, i0);  // the bit test uses the low 6 bits of i0
     }
   } else {
     int mlo = 0, mhi = 0;  // lane r keeps the mask of nodes [64r, 64r+64)
@@ -203,13 +204,10 @@ __device__ __forceinline__ void coop_pop(H& h, int n, int lane, PhaseTimer& ph, 
       const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane(mhi, (int)w);
       const unsigned long long rw = ((unsigned long long)hi << 32) | lo;
       m = (m << 1) | (uint32_t)((rw >> (i0 & 63)) & 1ull);
-      L++;
     }
   }
-  if ((len & 1) == 0 && m - 1 == two1) {  // the one node with a single (left) child, stl_heap.h:235-241
-    m = m << 1;
-    L++;
-  }
+  if ((len & 1) == 0 && m - 1 == two1) m = m << 1;  // the one node with a single (left) child, stl_heap.h:235-241
+  L = 31 - __clz((int)m);  // m spells the path behind a leading 1: its length is the depth reached
   // lane j (j <= L) owns the path node at depth j
   const int sh = L - lane;
   const int my_p = sh >= 0 ? (int)(m >> sh) - 1 : 0;
