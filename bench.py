@@ -319,13 +319,22 @@ def cpu_baseline(index, Q, K, EF, hw, gpu_labels, dtype="float32"):
     o.search(Q[:2000], K, EF, threads=1)
     qps1 = 2000 / (time.perf_counter() - t0)
     same = float((ol == gpu_labels).all(axis=1).mean())
+    cpu_model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
         "value": nq_done / t_used,
         "unit": "queries/s",
         "cores": threads,
         "kind": "port",
         "sample": "%d x the same %d-query batch on %d host threads (%s); single-thread: %.0f queries/s; "
-                  "GPU ids == CPU ids on %.2f%% of queries" % (reps, len(Q), threads, kind_note, qps1, same * 100),
+                  "GPU ids == CPU ids on %.2f%% of queries; host: %s, %d CPUs visible, %d usable (cgroup quota)"
+                  % (reps, len(Q), threads, kind_note, qps1, same * 100, cpu_model, os.cpu_count() or 0, hw),
     }
 
 
