@@ -127,8 +127,9 @@ struct fnv_index_s {
   int32_t* d_labels = nullptr;
   int num_cus = 0;
   // options
-  int64_t visited_factor = 27, visited_slots = 0, cand_factor = 2, cand_slots = 0, spill_entries = 16384,
-          blocks_per_cu = 0, visited_wide = 0, entry_kernel = 0;
+  int64_t visited_factor = 27, visited_slots = 0, visited_floor = 2048, occupancy_target = 13, cand_factor = 2,
+          cand_slots = 0, spill_entries = 16384, blocks_per_cu = 0, visited_wide = 0,
+          entry_kernel = 0;
   // workspace (grown on demand)
   uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status
   unsigned long long* d_phase = nullptr;  // profiling builds only
@@ -338,7 +339,9 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
       return fail(FNV_ERR_INVALID, "visited_slots must be 2^j or 3*2^j");
     if (value && value < 256) return fail(FNV_ERR_INVALID, "visited_slots must be at least 256");
     ix->visited_slots = value;
-  } else if (n == "cand_factor") ix->cand_factor = std::max<int64_t>(1, value);
+  } else if (n == "visited_floor") ix->visited_floor = std::max<int64_t>(256, value);
+  else if (n == "occupancy_target") ix->occupancy_target = value;
+  else if (n == "cand_factor") ix->cand_factor = std::max<int64_t>(1, value);
   else if (n == "cand_slots") ix->cand_slots = value;
   else if (n == "spill_entries") ix->spill_entries = std::max<int64_t>(1, value);
   else if (n == "blocks_per_cu") ix->blocks_per_cu = value;
@@ -396,33 +399,25 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
   const uint32_t per_iter = (uint32_t)(kCfgs[cfg].G * kCfgs[cfg].CU);
   p.q_chunks = (p.nchunks + per_iter - 1) / per_iter * per_iter;
 
-  {
-    // Visited-table geometry.  Slots = 2^j or 3*2^j.  16-bit tags whenever the per-bucket id range
-    // fits 14 bits: buckets = mult*2^k, t = nbits - k, need t <= 14 (mult 1) or t <= 15 (mult 3).
-    uint32_t nbits = 1;
-    while (nbits < 32 && (1ull << nbits) < ix->n_nodes) nbits++;
-    uint64_t want = ix->visited_slots ? (uint64_t)ix->visited_slots
-                                      : (uint64_t)ix->visited_factor * (uint64_t)p.B + 600;
-    want = std::max<uint64_t>(want, 256);
-    uint32_t slots = 256;
-    for (uint32_t base = 256;; base <<= 1) {  // candidates in increasing order: 2^j, 3*2^(j-1), 2^(j+1), ...
-      if (base >= want || base >= (1u << 15)) {
-        slots = base;
-        break;
-      }
-      if ((uint64_t)base / 2 * 3 >= want) {
-        slots = base / 2 * 3;
-        break;
-      }
-    }
-    if (ix->visited_slots) slots = (uint32_t)ix->visited_slots;
+  p.cand_slots = ix->cand_slots ? (uint32_t)ix->cand_slots : (uint32_t)(ix->cand_factor * p.B + 192);
+  p.cand_slots = std::max<uint32_t>(p.cand_slots, (uint32_t)p.B + 1);  // also hosts the final result list
+  p.spill_entries = (uint32_t)ix->spill_entries;
+  p.bitmap_words = (uint32_t)(((ix->n_nodes + 31) / 32 + 3) / 4 * 4);  // whole 16-byte groups: wide clears
+
+  const bool full = (p.nchunks % per_iter) == 0;  // rows are whole spans: the lean FULL kernels apply
+  kernel_fn kern = pick_kernel(ix->dtype, ix->metric, cfg, full);
+
+  // Visited-table geometry for a table of `slots` (2^j or 3*2^j) and the LDS layout that follows from it.
+  // 16-bit tags whenever the per-bucket id range fits 14 bits: buckets = mult*2^k, t = nbits - k, need
+  // t <= 14 (mult 1) or t <= 15 (mult 3).
+  uint32_t nbits = 1;
+  while (nbits < 32 && (1ull << nbits) < ix->n_nodes) nbits++;
+  auto lay_out = [&](uint32_t slots) -> uint32_t {
     const uint32_t mult = (slots % 3 == 0) ? 3u : 1u;
     uint32_t k = 0;
     for (uint32_t b = slots / 4 / mult; b > 1; b >>= 1) k++;
-    bool can16 = !ix->visited_wide && nbits <= 30 && k <= nbits && (nbits - k) <= (mult == 3 ? 15u : 14u);
-    if (!can16 && mult == 3) {  // the 32-bit table needs a power of two
-      slots = pow2_ceil(slots);
-    }
+    const bool can16 = !ix->visited_wide && nbits <= 30 && k <= nbits && (nbits - k) <= (mult == 3 ? 15u : 14u);
+    if (!can16 && mult == 3) slots = pow2_ceil(slots);  // the 32-bit table needs a power of two
     p.vis_slots = slots;
     p.vis_tag16 = can16 ? 1u : 0u;
     p.vis_mult = mult;
@@ -433,33 +428,68 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
     p.vis_shift = 32;
     for (uint32_t sft = p.vis_slots; sft > 1; sft >>= 1) p.vis_shift--;
     p.vis_limit = p.vis_slots / 4 * 3;
-  }
-  p.cand_slots = ix->cand_slots ? (uint32_t)ix->cand_slots : (uint32_t)(ix->cand_factor * p.B + 192);
-  p.cand_slots = std::max<uint32_t>(p.cand_slots, (uint32_t)p.B + 1);  // also hosts the final result list
-  p.spill_entries = (uint32_t)ix->spill_entries;
-  p.bitmap_words = (uint32_t)((ix->n_nodes + 31) / 32);
 
-  auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
-  uint32_t off = 0;
-  p.off_q = off;
-  off = align16(off + p.q_chunks * 16);
-  p.off_nbr = off + 8;  // heap arrays start at 16n + 8: child pairs are 16-byte aligned
-  off = align16(off + 8 + ((uint32_t)p.B + 2) * 8);
-  p.off_cand = off + 8;
-  off = align16(off + 8 + (p.cand_slots + 1) * 8);
-  p.off_vis = off;
-  off = align16(off + p.vis_bytes);
-  p.off_stage_ids = off;
-  off = align16(off + (WAVE + 1) * 4);  // + one write-only slot for lanes with nothing to stage
-  p.off_ovf = off;
-  off = align16(off + (OVF_LIST + 2) * 4);
-  const uint32_t lds_bytes = off;
+    auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+    uint32_t off = 0;
+    p.off_q = off;
+    off = align16(off + p.q_chunks * 16);
+    p.off_nbr = off + 8;  // heap arrays start at 16n + 8: child pairs are 16-byte aligned
+    off = align16(off + 8 + ((uint32_t)p.B + 2) * 8);
+    p.off_cand = off + 8;
+    off = align16(off + 8 + (p.cand_slots + 1) * 8);
+    p.off_vis = off;
+    off = align16(off + p.vis_bytes);
+    p.off_stage_ids = off;
+    off = align16(off + (WAVE + 1) * 4);  // + one write-only slot for lanes with nothing to stage
+    p.off_ovf = off;
+    off = align16(off + (OVF_LIST + 2) * 4);
+    return off;
+  };
+  auto resident = [&](uint32_t lds) -> int {  // query slots one CU can hold with this much LDS each
+    if (lds > 160u * 1024u) return 0;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kern, WAVE, lds) != hipSuccess) n = 0;
+    return n;
+  };
+  // Table sizes, ascending: 256, 384, 512, 768, ...  The roomy size (visited_factor * B + 600, <= 60 % load
+  // on the reference workloads) keeps every id in LDS; but LDS is also what limits how many queries a CU
+  // keeps in flight, and a lone wave issues slowly -- below ~13 resident queries per CU the loss of
+  // latency hiding costs more than sending part of the ids to the HBM bitmap (measured: profiles/
+  // r1_visited_sizing.md).  So: the largest size <= roomy that still leaves `occupancy_target` queries
+  // per CU, but never below visited_floor slots.
+  uint32_t lds_bytes;
+  if (ix->visited_slots) {
+    lds_bytes = lay_out((uint32_t)ix->visited_slots);
+  } else {
+    const uint64_t want = std::max<uint64_t>((uint64_t)ix->visited_factor * (uint64_t)p.B + 600, 256);
+    std::vector<uint32_t> sizes;
+    for (uint32_t base = 256; base <= (1u << 15); base <<= 1) {
+      sizes.push_back(base);
+      if (base >= want) break;
+      if (base < (1u << 15)) {
+        sizes.push_back(base / 2 * 3);
+        if ((uint64_t)base / 2 * 3 >= want) break;
+      }
+    }
+    size_t pick = sizes.size() - 1;  // roomy
+    lds_bytes = lay_out(sizes[pick]);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)std::min<uint32_t>(lds_bytes, 160u * 1024u));
+    const int target = (int)ix->occupancy_target;
+    const uint32_t roomy_tag16 = p.vis_tag16;
+    while (pick > 0 && sizes[pick - 1] >= (uint32_t)ix->visited_floor && resident(lds_bytes) < target) {
+      lds_bytes = lay_out(sizes[pick - 1]);
+      if (p.vis_tag16 != roomy_tag16) {  // too few buckets for 16-bit tags at this id width: stop above it
+        lds_bytes = lay_out(sizes[pick]);
+        break;
+      }
+      pick--;
+    }
+  }
   if (lds_bytes > 160u * 1024u)
     return fail(FNV_ERR_INVALID, "ef_search too large for the on-chip beam state (needs " + std::to_string(lds_bytes) +
                                      " bytes of LDS, 163840 available); lower ef_search or the *_slots options");
 
-  const bool full = (p.nchunks % per_iter) == 0;  // rows are whole spans: the lean FULL kernels apply
-  kernel_fn kern = pick_kernel(ix->dtype, ix->metric, cfg, full);
   HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   int bpc = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, WAVE, lds_bytes));

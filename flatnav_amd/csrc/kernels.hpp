@@ -355,7 +355,8 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
       if (p.vis_tag16 && listed <= OVF_LIST) {  // few ids: clear just their words
         if ((uint32_t)lane < listed) bitmap[ovf_list[1 + lane] >> 5] = 0u;
       } else {
-        for (uint32_t i = lane; i < p.bitmap_words; i += WAVE) bitmap[i] = 0u;
+        uint4* b4 = reinterpret_cast<uint4*>(bitmap);
+        for (uint32_t i = lane; i < p.bitmap_words / 4; i += WAVE) b4[i] = make_uint4(0u, 0u, 0u, 0u);
       }
       __threadfence();
     }

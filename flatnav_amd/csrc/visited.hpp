@@ -97,6 +97,9 @@ __device__ __forceinline__ bool visited_insert_tag16(uint32_t* tab, const Search
         used_bitmap = true;
         if (!(old & bit)) {
           const uint32_t pos = atomicAdd(&ovf_list[0], 1u);
+          // the first OVF_LIST ids are remembered so that a lightly used bitmap is cleared word by word; past
+          // that the whole bitmap is cleared with wide sequential stores (measured faster than scattered
+          // 4-byte clears driven by a longer list kept in HBM)
           if (pos < OVF_LIST) ovf_list[1 + pos] = id;
           isnew = 1u;
         }

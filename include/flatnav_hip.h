@@ -94,9 +94,13 @@ int fnv_index_info(fnv_index_t index, uint64_t info[8]);
 int fnv_index_free(fnv_index_t index);
 
 /* Tuning / test knobs (all optional).  Names:
- *   "visited_factor"  LDS visited-table slots = visited_factor * beam width + 600, rounded up to 2^j or
- *                     3*2^j (default 27)
- *   "visited_slots"   force the LDS visited-table size (2^j or 3*2^j; 0 = from factor)
+ *   "visited_factor"  roomy LDS visited-table size = visited_factor * beam width + 600 slots, rounded up to
+ *                     2^j or 3*2^j (default 27); used as is while "occupancy_target" queries fit per CU
+ *   "occupancy_target" resident queries per CU below which the table is shrunk step by step (ids that
+ *                     find both their buckets full go to the per-slot HBM bitmap, results unchanged);
+ *                     default 13, 0 = never shrink
+ *   "visited_floor"   the table is not shrunk below this many slots (default 2048)
+ *   "visited_slots"   force the LDS visited-table size (2^j or 3*2^j; 0 = automatic as above)
  *   "cand_factor"     LDS candidate-heap capacity = cand_factor * beam width + 192 (default 2)
  *   "cand_slots"      force the LDS candidate-heap capacity (0 = from factor)
  *   "spill_entries"   per-slot HBM spill capacity of the candidate heap (default 16384)
