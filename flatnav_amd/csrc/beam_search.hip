@@ -121,7 +121,8 @@ struct fnv_index_s {
   int device = 0;
   int dtype = FNV_DTYPE_FLOAT32, metric = FNV_METRIC_L2;
   uint32_t M = 0, dim = 0, row_bytes = 0;
-  uint64_t n_nodes = 0;
+  uint64_t n_nodes = 0;   // live nodes: what a search sees (entry scan, id range)
+  uint64_t capacity = 0;  // rows the device buffers hold (>= n_nodes; grows never)
   uint8_t* d_vectors = nullptr;
   uint32_t* d_links = nullptr;
   int32_t* d_labels = nullptr;
@@ -129,7 +130,7 @@ struct fnv_index_s {
   // options
   int64_t visited_factor = 27, visited_slots = 0, visited_floor = 2048, occupancy_target = 13, cand_factor = 2,
           cand_slots = 0, spill_entries = 16384, blocks_per_cu = 0, visited_wide = 0,
-          entry_kernel = 0;
+          entry_kernel = 0, output_node_ids = 0;
   // workspace (grown on demand)
   uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status
   unsigned long long* d_phase = nullptr;  // profiling builds only
@@ -137,6 +138,8 @@ struct fnv_index_s {
   size_t entry_bytes = 0;
   uint32_t* d_bitmap = nullptr;
   size_t bitmap_bytes = 0;
+  void* d_linkstage = nullptr;  // fnv_index_write_links: [count] ids | [count][M] rows | bad flag
+  size_t linkstage_bytes = 0;
   unsigned long long* d_spill = nullptr;
   size_t spill_bytes = 0;
   // staging for the host-buffer entry point
@@ -182,9 +185,9 @@ int validate_geometry(uint32_t M, uint64_t n_nodes, int data_type, int metric, u
 
 int alloc_buffers(fnv_index_s* ix) {
   HIP_TRY(hipSetDevice(ix->device));
-  HIP_TRY(hipMalloc(&ix->d_vectors, ix->n_nodes * (uint64_t)ix->row_bytes));
-  HIP_TRY(hipMalloc(&ix->d_links, ix->n_nodes * (uint64_t)ix->M * 4));
-  HIP_TRY(hipMalloc(&ix->d_labels, ix->n_nodes * 4));
+  HIP_TRY(hipMalloc(&ix->d_vectors, ix->capacity * (uint64_t)ix->row_bytes));
+  HIP_TRY(hipMalloc(&ix->d_links, ix->capacity * (uint64_t)ix->M * 4));
+  HIP_TRY(hipMalloc(&ix->d_labels, ix->capacity * 4));
   return index_common_init(ix);
 }
 
@@ -192,6 +195,48 @@ uint32_t pow2_ceil(uint64_t v) {
   uint32_t p = 1;
   while (p < v) p <<= 1;
   return p;
+}
+
+// Copy AoS node records [data][M links][label] (reference Index.h:61-63) for nodes first..first+count-1 into the
+// SoA device buffers, 256 MB at a time.  Link ids >= id_limit are flagged (and replaced by a self-loop).
+int write_nodes_impl(fnv_index_s* ix, uint64_t first_node, uint64_t count_nodes, const void* aos_rows,
+                     uint64_t node_size, uint64_t data_size, uint64_t id_limit, int* bad_out) {
+  HIP_TRY(hipSetDevice(ix->device));
+  const uint64_t chunk_nodes = std::max<uint64_t>(1, (256ull << 20) / node_size);
+  uint8_t* d_stage = nullptr;
+  int* d_bad = nullptr;
+  auto cleanup = [&]() {
+    if (d_stage) (void)hipFree(d_stage);
+    if (d_bad) (void)hipFree(d_bad);
+  };
+#define UP_TRY(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess) {                                                                            \
+      cleanup();                                                                                       \
+      return fail(FNV_ERR_NO_DEVICE, std::string(#expr) + " failed: " + hipGetErrorString(_e));       \
+    }                                                                                                  \
+  } while (0)
+  UP_TRY(hipMalloc(&d_stage, std::min(chunk_nodes, count_nodes) * node_size));
+  UP_TRY(hipMalloc(&d_bad, sizeof(int)));
+  UP_TRY(hipMemset(d_bad, 0, sizeof(int)));
+  const int word_ok = (node_size % 4 == 0 && data_size % 4 == 0) ? 1 : 0;
+  for (uint64_t done = 0; done < count_nodes; done += chunk_nodes) {
+    const uint64_t count = std::min(chunk_nodes, count_nodes - done);
+    const uint64_t first = first_node + done;
+    UP_TRY(hipMemcpy(d_stage, (const uint8_t*)aos_rows + done * node_size, count * node_size, hipMemcpyHostToDevice));
+    const uint64_t units = count * (word_ok ? ix->row_bytes / 4 : ix->row_bytes);
+    hipLaunchKernelGGL(relayout_vectors_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, 0, d_stage,
+                       node_size, data_size, ix->row_bytes, first, count, ix->d_vectors, word_ok);
+    hipLaunchKernelGGL(relayout_links_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, d_stage,
+                       node_size, data_size, ix->M, first, count, id_limit, ix->d_links, ix->d_labels, d_bad);
+    UP_TRY(hipGetLastError());
+    UP_TRY(hipDeviceSynchronize());
+  }
+  UP_TRY(hipMemcpy(bad_out, d_bad, sizeof(int), hipMemcpyDeviceToHost));
+  cleanup();
+#undef UP_TRY
+  return FNV_OK;
 }
 
 }  // namespace
@@ -227,6 +272,7 @@ int fnv_index_alloc(uint32_t M, uint64_t n_nodes, int data_type, int metric, uin
   ix->M = M;
   ix->dim = dim;
   ix->n_nodes = n_nodes;
+  ix->capacity = n_nodes;
   ix->row_bytes = (uint32_t)((dim * dtype_size(data_type) + 15) / 16 * 16);
   rc = alloc_buffers(ix);
   if (rc) {
@@ -248,41 +294,12 @@ int fnv_index_upload(const void* aos_blob, uint64_t node_size, uint64_t data_siz
   rc = fnv_index_alloc(M, n_nodes, data_type, metric, dim, device, &ix);
   if (rc) return rc;
 
-  const uint64_t chunk_nodes = std::max<uint64_t>(1, (256ull << 20) / node_size);
-  uint8_t* d_stage = nullptr;
-  int* d_bad = nullptr;
-  auto cleanup = [&]() {
-    if (d_stage) (void)hipFree(d_stage);
-    if (d_bad) (void)hipFree(d_bad);
-  };
-#define UP_TRY(expr)                                                                                   \
-  do {                                                                                                 \
-    hipError_t _e = (expr);                                                                            \
-    if (_e != hipSuccess) {                                                                            \
-      cleanup();                                                                                       \
-      fnv_index_free(ix);                                                                              \
-      return fail(FNV_ERR_NO_DEVICE, std::string(#expr) + " failed: " + hipGetErrorString(_e));       \
-    }                                                                                                  \
-  } while (0)
-  UP_TRY(hipMalloc(&d_stage, std::min(chunk_nodes, n_nodes) * node_size));
-  UP_TRY(hipMalloc(&d_bad, sizeof(int)));
-  UP_TRY(hipMemset(d_bad, 0, sizeof(int)));
-  const int word_ok = (node_size % 4 == 0 && data_size % 4 == 0) ? 1 : 0;
-  for (uint64_t first = 0; first < n_nodes; first += chunk_nodes) {
-    const uint64_t count = std::min(chunk_nodes, n_nodes - first);
-    UP_TRY(hipMemcpy(d_stage, (const uint8_t*)aos_blob + first * node_size, count * node_size, hipMemcpyHostToDevice));
-    const uint64_t units = count * (word_ok ? ix->row_bytes / 4 : ix->row_bytes);
-    hipLaunchKernelGGL(relayout_vectors_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, 0, d_stage,
-                       node_size, data_size, ix->row_bytes, first, count, ix->d_vectors, word_ok);
-    hipLaunchKernelGGL(relayout_links_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, d_stage,
-                       node_size, data_size, M, first, count, n_nodes, ix->d_links, ix->d_labels, d_bad);
-    UP_TRY(hipGetLastError());
-    UP_TRY(hipDeviceSynchronize());
-  }
   int bad = 0;
-  UP_TRY(hipMemcpy(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost));
-  cleanup();
-#undef UP_TRY
+  rc = write_nodes_impl(ix, 0, n_nodes, aos_blob, node_size, data_size, n_nodes, &bad);
+  if (rc) {
+    fnv_index_free(ix);
+    return rc;
+  }
   if (bad) {
     fnv_index_free(ix);
     return fail(FNV_ERR_RUNTIME, "index blob holds link ids outside [0, n_nodes)");
@@ -296,9 +313,9 @@ int fnv_index_device_buffers(fnv_index_t ix, void* ptrs[3], uint64_t sizes[3]) {
   ptrs[0] = ix->d_vectors;
   ptrs[1] = ix->d_links;
   ptrs[2] = ix->d_labels;
-  sizes[0] = ix->n_nodes * (uint64_t)ix->row_bytes;
-  sizes[1] = ix->n_nodes * (uint64_t)ix->M * 4;
-  sizes[2] = ix->n_nodes * 4;
+  sizes[0] = ix->capacity * (uint64_t)ix->row_bytes;
+  sizes[1] = ix->capacity * (uint64_t)ix->M * 4;
+  sizes[2] = ix->capacity * 4;
   return FNV_OK;
 }
 
@@ -311,7 +328,7 @@ int fnv_index_info(fnv_index_t ix, uint64_t info[8]) {
   info[4] = ix->dim;
   info[5] = (uint64_t)ix->metric;
   info[6] = (uint64_t)ix->device;
-  info[7] = ix->n_nodes * ((uint64_t)ix->row_bytes + 4ull * ix->M + 4) + ix->bitmap_bytes + ix->spill_bytes;
+  info[7] = ix->capacity * ((uint64_t)ix->row_bytes + 4ull * ix->M + 4) + ix->bitmap_bytes + ix->spill_bytes;
   return FNV_OK;
 }
 
@@ -319,13 +336,66 @@ int fnv_index_free(fnv_index_t ix) {
   if (!ix) return FNV_OK;
   (void)hipSetDevice(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_bitmap, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase, ix->d_entry};
+  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_bitmap, ix->d_linkstage, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase, ix->d_entry};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (ix->ev0) (void)hipEventDestroy(ix->ev0);
   if (ix->ev1) (void)hipEventDestroy(ix->ev1);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
   delete ix;
+  return FNV_OK;
+}
+
+int fnv_index_set_live_nodes(fnv_index_t ix, uint64_t n_live) {
+  if (!ix) return fail(FNV_ERR_INVALID, "null argument");
+  if (n_live == 0 || n_live > ix->capacity)
+    return fail(FNV_ERR_INVALID, "live node count must be in [1, capacity]");
+  std::lock_guard<std::mutex> lock(ix->mu);
+  ix->n_nodes = n_live;
+  return FNV_OK;
+}
+
+int fnv_index_write_nodes(fnv_index_t ix, uint64_t first_node, uint64_t count, const void* aos_rows,
+                          uint64_t node_size, uint64_t data_size) {
+  if (!ix || (!aos_rows && count)) return fail(FNV_ERR_INVALID, "null argument");
+  if (data_size != (uint64_t)ix->dim * dtype_size(ix->dtype) || node_size != data_size + 4ull * ix->M + 4)
+    return fail(FNV_ERR_INVALID, "node geometry does not match [data][M links][label] (Index.h:176)");
+  if (first_node > ix->capacity || count > ix->capacity - first_node)
+    return fail(FNV_ERR_RUNTIME, "Maximum number of nodes reached. (device index capacity)");
+  if (count == 0) return FNV_OK;
+  std::lock_guard<std::mutex> lock(ix->mu);
+  int bad = 0;
+  int rc = write_nodes_impl(ix, first_node, count, aos_rows, node_size, data_size, ix->capacity, &bad);
+  if (rc) return rc;
+  if (bad) return fail(FNV_ERR_RUNTIME, "node records hold link ids outside [0, capacity)");
+  return FNV_OK;
+}
+
+int fnv_index_write_links(fnv_index_t ix, const uint32_t* node_ids, const uint32_t* link_rows, uint64_t count) {
+  if (!ix || ((!node_ids || !link_rows) && count)) return fail(FNV_ERR_INVALID, "null argument");
+  if (count == 0) return FNV_OK;
+  std::lock_guard<std::mutex> lock(ix->mu);
+  HIP_TRY(hipSetDevice(ix->device));
+  const size_t need = (size_t)count * (4 + 4ull * ix->M) + sizeof(int);
+  if (need > ix->linkstage_bytes) {
+    if (ix->d_linkstage) HIP_TRY(hipFree(ix->d_linkstage));
+    ix->d_linkstage = nullptr;
+    ix->linkstage_bytes = 0;
+    HIP_TRY(hipMalloc(&ix->d_linkstage, need + need / 2));
+    ix->linkstage_bytes = need + need / 2;
+  }
+  uint32_t* d_ids = (uint32_t*)ix->d_linkstage;
+  uint32_t* d_rows = d_ids + count;
+  int* d_bad = (int*)(d_rows + count * ix->M);
+  HIP_TRY(hipMemcpy(d_ids, node_ids, count * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_rows, link_rows, count * 4ull * ix->M, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(d_bad, 0, sizeof(int)));
+  hipLaunchKernelGGL(scatter_links_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, d_ids, d_rows, count,
+                     ix->M, ix->capacity, ix->d_links, d_bad);
+  HIP_TRY(hipGetLastError());
+  int bad = 0;
+  HIP_TRY(hipMemcpy(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost));
+  if (bad) return fail(FNV_ERR_RUNTIME, "link rows hold node ids outside [0, capacity)");
   return FNV_OK;
 }
 
@@ -347,6 +417,7 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   else if (n == "blocks_per_cu") ix->blocks_per_cu = value;
   else if (n == "visited_wide") ix->visited_wide = value;
   else if (n == "entry_kernel") ix->entry_kernel = value;
+  else if (n == "output_node_ids") ix->output_node_ids = value;
   else return fail(FNV_ERR_INVALID, "unknown option: " + n);
   return FNV_OK;
 }
@@ -369,7 +440,7 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
   memset(&p, 0, sizeof(p));
   p.vectors = ix->d_vectors;
   p.links = ix->d_links;
-  p.labels = ix->d_labels;
+  p.labels = ix->output_node_ids ? nullptr : ix->d_labels;
   p.queries = (const uint8_t*)d_queries;
   p.out_dist = d_out_dist;
   p.out_labels = d_out_labels;
@@ -402,7 +473,7 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
   p.cand_slots = ix->cand_slots ? (uint32_t)ix->cand_slots : (uint32_t)(ix->cand_factor * p.B + 192);
   p.cand_slots = std::max<uint32_t>(p.cand_slots, (uint32_t)p.B + 1);  // also hosts the final result list
   p.spill_entries = (uint32_t)ix->spill_entries;
-  p.bitmap_words = (uint32_t)(((ix->n_nodes + 31) / 32 + 3) / 4 * 4);  // whole 16-byte groups: wide clears
+  p.bitmap_words = (uint32_t)(((ix->capacity + 31) / 32 + 3) / 4 * 4);  // whole 16-byte groups: wide clears
 
   const bool full = (p.nchunks % per_iter) == 0;  // rows are whole spans: the lean FULL kernels apply
   kernel_fn kern = pick_kernel(ix->dtype, ix->metric, cfg, full);
@@ -411,7 +482,7 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
   // 16-bit tags whenever the per-bucket id range fits 14 bits: buckets = mult*2^k, t = nbits - k, need
   // t <= 14 (mult 1) or t <= 15 (mult 3).
   uint32_t nbits = 1;
-  while (nbits < 32 && (1ull << nbits) < ix->n_nodes) nbits++;
+  while (nbits < 32 && (1ull << nbits) < ix->capacity) nbits++;
   auto lay_out = [&](uint32_t slots) -> uint32_t {
     const uint32_t mult = (slots % 3 == 0) ? 3u : 1u;
     uint32_t k = 0;

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
       if (k < cnt && !err) {
         fnv_stl::Entry e = unpack(res[k]);
         od = e.key;
-        ol = p.labels[e.val];
+        ol = p.labels ? p.labels[e.val] : (int32_t)e.val;  // null: construction wants node ids
       }
       p.out_dist[(uint64_t)qi * K + k] = od;
       p.out_labels[(uint64_t)qi * K + k] = ol;
@@ -460,6 +460,34 @@ __global__ void relayout_links_kernel(const uint8_t* __restrict__ aos, uint64_t 
   int32_t lab;
   memcpy(&lab, base + (uint64_t)M * 4, 4);
   labels[first_node + node] = lab;
+}
+
+// Incremental construction: overwrite the link rows of `count` scattered nodes (same normalisation as above).
+__global__ void scatter_links_kernel(const uint32_t* __restrict__ node_ids, const uint32_t* __restrict__ rows,
+                                     uint64_t count, uint32_t M, uint64_t id_limit, uint32_t* __restrict__ links,
+                                     int* bad_flag) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= count) return;
+  const uint32_t self = node_ids[r];
+  if ((uint64_t)self >= id_limit) {
+    atomicExch(bad_flag, 1);
+    return;
+  }
+  const uint32_t* in = rows + r * M;
+  uint32_t* out = links + (uint64_t)self * M;
+  for (uint32_t i = 0; i < M; i++) {
+    uint32_t id = in[i];
+    if ((uint64_t)id >= id_limit) {
+      atomicExch(bad_flag, 1);
+      id = self;
+    }
+    for (uint32_t j = 0; j < i; j++)
+      if (in[j] == id) {
+        id = self;
+        break;
+      }
+    out[i] = id;
+  }
 }
 
 }  // namespace fnv_dev

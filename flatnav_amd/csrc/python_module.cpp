@@ -58,7 +58,9 @@ class PyIndex : public std::enable_shared_from_this<PyIndex<dist_t, kType>> {
   }
 
   // add(data, ef_construction, num_initializations=100, labels=None)   [bindings.cpp:64-119, 326-335]
-  void add(const py::array& data_any, int ef_construction, int num_initializations, py::object labels) {
+  // device=True (extension): the insertions' beam searches run on the GPU in batches (Index::addBatchDevice).
+  void add(const py::array& data_any, int ef_construction, int num_initializations, py::object labels, bool device,
+           uint32_t device_max_batch) {
     dense_array<element_t> data = data_any.cast<dense_array<element_t>>();
     if (data.ndim() != 2 || data.shape(1) != _dim)
       throw std::invalid_argument("Data has incorrect dimensions. data.ndim() = `" + std::to_string(data.ndim()) +
@@ -78,7 +80,13 @@ class PyIndex : public std::enable_shared_from_this<PyIndex<dist_t, kType>> {
     }
     void* raw = const_cast<element_t*>(data.data());
     py::gil_scoped_release release;  // the builder spawns its own threads
-    _index->template addBatch<element_t>(raw, ids, ef_construction, num_initializations);
+    if (device) {
+      typename index_t::DeviceBuildOptions opt;
+      if (device_max_batch) opt.max_batch = device_max_batch;
+      _index->template addBatchDevice<element_t>(raw, ids, ef_construction, num_initializations, opt);
+    } else {
+      _index->template addBatch<element_t>(raw, ids, ef_construction, num_initializations);
+    }
   }
 
   // allocate_nodes(data) -> self   [bindings.cpp:308-324]: vectors only, no edges (used before
@@ -177,8 +185,9 @@ void bindIndex(py::module_& m, const char* name) {
   using T = PyIndex<dist_t, kType>;
   py::class_<T, std::shared_ptr<T>>(m, name)
       .def("add", &T::add, py::arg("data"), py::arg("ef_construction"), py::arg("num_initializations") = 100,
-           py::arg("labels") = py::none(),
-           "Insert vectors (rows of `data`, cast to the index data type) into the graph.")
+           py::arg("labels") = py::none(), py::kw_only(), py::arg("device") = false, py::arg("device_max_batch") = 0,
+           "Insert vectors (rows of `data`, cast to the index data type) into the graph.  device=True: the "
+           "insertions' beam searches run on the GPU in batches (same graph family, not the same bytes).")
       .def("allocate_nodes", &T::allocateNodes, py::arg("data"),
            "Store vectors without creating edges (follow with build_graph_links).")
       .def("search_single", &T::searchSingle, py::arg("query"), py::arg("K"), py::arg("ef_search"),

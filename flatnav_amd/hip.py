@@ -23,6 +23,7 @@ C_ABI_SYMBOLS = [
     "fnv_last_error", "fnv_version", "fnv_device_count", "fnv_index_upload", "fnv_index_alloc",
     "fnv_index_device_buffers", "fnv_index_info", "fnv_index_free", "fnv_set_option", "fnv_search_batch",
     "fnv_search_batch_device", "fnv_search_status", "fnv_last_kernel_ms", "fnv_last_launch_geometry",
+    "fnv_index_set_live_nodes", "fnv_index_write_nodes", "fnv_index_write_links",
 ]
 
 _lib = None
@@ -55,6 +56,9 @@ def lib() -> C.CDLL:
     L.fnv_index_device_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.fnv_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.fnv_index_free.argtypes = [C.c_void_p]
+    L.fnv_index_set_live_nodes.argtypes = [C.c_void_p, C.c_uint64]
+    L.fnv_index_write_nodes.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]
+    L.fnv_index_write_links.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.fnv_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.fnv_search_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
     L.fnv_search_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int] + [
@@ -137,6 +141,24 @@ class DeviceIndex:
         sizes = (C.c_uint64 * 3)()
         check(lib().fnv_index_device_buffers(self._h, ptrs, sizes))
         return [(int(ptrs[i] or 0), int(sizes[i])) for i in range(3)]
+
+    # ---- incremental construction -------------------------------------------------------------
+    def set_live_nodes(self, n_live: int) -> None:
+        check(lib().fnv_index_set_live_nodes(self._h, int(n_live)))
+        self.n_nodes = int(n_live)
+
+    def write_nodes(self, first_node: int, rows: np.ndarray, node_size: int, data_size: int) -> None:
+        """rows: uint8 blob of whole AoS node records for nodes first_node, first_node+1, ..."""
+        rows = np.ascontiguousarray(rows).view(np.uint8).reshape(-1)
+        if rows.size % node_size:
+            raise ValueError("rows must hold whole node records")
+        check(lib().fnv_index_write_nodes(self._h, int(first_node), rows.size // node_size, rows.ctypes.data,
+                                          node_size, data_size))
+
+    def write_links(self, node_ids: np.ndarray, link_rows: np.ndarray) -> None:
+        ids = np.ascontiguousarray(node_ids, dtype=np.uint32).reshape(-1)
+        rows = np.ascontiguousarray(link_rows, dtype=np.uint32).reshape(ids.size, self.M)
+        check(lib().fnv_index_write_links(self._h, ids.ctypes.data, rows.ctypes.data, ids.size))
 
     def set_option(self, name: str, value: int) -> None:
         check(lib().fnv_set_option(self._h, name.encode(), int(value)))

@@ -162,6 +162,7 @@ class Index {
   mutable std::mutex _device_guard;
   mutable fnv_index_t _device_index = nullptr;
   mutable bool _device_stale = true;
+  mutable size_t _device_capacity = 0;  // rows allocated on the device (== node count unless built there)
   int _device_ordinal = 0;
 
   Index() = default;
@@ -340,6 +341,27 @@ class Index {
                                                 static_cast<int>(_data_type), metric,
                                                 static_cast<uint32_t>(const_cast<Index*>(this)->_distance->dimension()),
                                                 _device_ordinal, &_device_index));
+    _device_capacity = _cur_num_nodes;
+    _device_stale = false;
+  }
+
+  int deviceMetric() { return _distance->metricType() == MetricType::L2 ? FNV_METRIC_L2 : FNV_METRIC_IP; }
+
+  // Device index with room for every node the store can hold, holding nodes [0, _cur_num_nodes): what the
+  // device-assisted builder appends to.
+  void ensureDeviceAtCapacity() {
+    if (_device_index && !_device_stale && _device_capacity == _max_node_count) return;
+    if (_device_index) {
+      fnv_index_free(_device_index);
+      _device_index = nullptr;
+    }
+    detail::throwOnDeviceError(fnv_index_alloc(static_cast<uint32_t>(_M), _max_node_count, static_cast<int>(_data_type),
+                                               deviceMetric(), static_cast<uint32_t>(_distance->dimension()),
+                                               _device_ordinal, &_device_index));
+    _device_capacity = _max_node_count;
+    detail::throwOnDeviceError(
+        fnv_index_write_nodes(_device_index, 0, _cur_num_nodes, _index_memory.get(), _node_size_bytes, _data_size_bytes));
+    detail::throwOnDeviceError(fnv_index_set_live_nodes(_device_index, _cur_num_nodes));
     _device_stale = false;
   }
 
@@ -446,6 +468,123 @@ class Index {
       return;
     }
     flatnav::executeInParallel(0, total, _num_threads, insertRow);
+  }
+
+  // ---- device-assisted construction (new) --------------------------------------
+  // Same insertion rule as add() -- beam search of width ef_construction over the nodes present, diversity
+  // pruning to M/2, back-links with re-pruning (reference Index.h:353-378, 714-834) -- but the beam searches
+  // of a whole batch of new points run as ONE GPU launch (the search kernel, node ids as output) against the
+  // graph as it stood before the batch; pruning and wiring stay on the host threads.  Points of one batch do
+  // not see each other as candidates (later arrivals still link back to them), so batches are kept small
+  // relative to the graph: at most cur/growth_divisor points, capped at max_batch; the first `bootstrap`
+  // points take the host path.  The result is a graph of the same family and search quality -- not the
+  // byte-identical one add() builds with one thread (the reference's own multi-threaded build is not
+  // reproducible either).
+  struct DeviceBuildOptions {
+    uint32_t max_batch = 32768;
+    uint32_t bootstrap = 2048;
+    uint32_t growth_divisor = 4;
+  };
+
+  template <typename data_type>
+  void addBatchDevice(void* data, std::vector<label_t>& labels, int ef_construction, int num_initializations = 100,
+                      DeviceBuildOptions opt = DeviceBuildOptions()) {
+    if (num_initializations <= 0) throw std::invalid_argument("num_initializations must be greater than 0.");
+    if (ef_construction <= 0) throw std::invalid_argument("ef_construction must be positive");
+    const uint64_t total = labels.size();
+    const uint64_t dim = _distance->dimension();
+    if (_cur_num_nodes + total > _max_node_count)
+      throw std::runtime_error(
+          "Maximum number of nodes reached. Consider increasing the `max_node_count` parameter to create a larger "
+          "index.");
+    auto rowPtr = [&](uint64_t row) { return static_cast<void*>(static_cast<data_type*>(data) + row * dim); };
+    uint64_t row = 0;
+    if (_cur_num_nodes < opt.bootstrap) {  // too small a graph to be worth a launch: host insertions
+      const uint64_t nb = std::min<uint64_t>(total, opt.bootstrap - _cur_num_nodes);
+      auto insertRow = [&](uint32_t r) {
+        label_t label = labels[r];
+        this->add(rowPtr(r), label, ef_construction, num_initializations);
+      };
+      if (_num_threads == 1) for (uint32_t r = 0; r < nb; ++r) insertRow(r);
+      else flatnav::executeInParallel(0, static_cast<uint32_t>(nb), _num_threads, insertRow);
+      row = nb;
+    }
+    if (row == total) return;
+
+    std::lock_guard<std::mutex> dev_lock(_device_guard);
+    ensureDeviceAtCapacity();
+    detail::throwOnDeviceError(fnv_set_option(_device_index, "output_node_ids", 1));
+    struct RestoreLabels {
+      fnv_index_t ix;
+      ~RestoreLabels() { fnv_set_option(ix, "output_node_ids", 0); }
+    } restore{_device_index};
+
+    const int width = ef_construction;
+    const int keep = std::max(static_cast<int>(_M / 2), 1);
+    std::vector<float> beam_dist;
+    std::vector<int32_t> beam_ids, beam_count;
+    std::vector<uint64_t> beam_evals;
+    std::vector<node_id_t> touched, link_rows;
+    std::mutex touched_guard;
+    while (row < total) {
+      const uint64_t cur = _cur_num_nodes;
+      const uint64_t batch = std::min<uint64_t>(
+          {total - row, opt.max_batch, std::max<uint64_t>(256, cur / std::max<uint32_t>(1, opt.growth_divisor))});
+      // 1. store the new nodes (vector, label, empty link row) and mirror them to the device; searches
+      //    still see only the `cur` nodes that are wired.
+      for (uint64_t i = 0; i < batch; ++i) {
+        node_id_t id;
+        allocateNode(rowPtr(row + i), labels[row + i], id);
+      }
+      detail::throwOnDeviceError(fnv_index_write_nodes(_device_index, cur, batch, nodeData(static_cast<node_id_t>(cur)),
+                                                       _node_size_bytes, _data_size_bytes));
+      // 2. the beam searches of the batch: one launch, full beams back (node ids, ascending distance)
+      beam_dist.resize(batch * width);
+      beam_ids.resize(batch * width);
+      beam_count.resize(batch);
+      beam_evals.resize(batch);
+      detail::throwOnDeviceError(fnv_search_batch(_device_index, rowPtr(row),
+                                                  batch, width, width, num_initializations, beam_dist.data(),
+                                                  beam_ids.data(), beam_count.data(), beam_evals.data(), nullptr));
+      // 3. prune + wire on the host threads
+      touched.clear();
+      auto wire = [&](uint32_t i) {
+        auto scratch = borrowScratch();
+        detail::KeyHeap& beam = scratch->beam;
+        beam.clear();
+        const float* bd = beam_dist.data() + static_cast<uint64_t>(i) * width;
+        const int32_t* bi = beam_ids.data() + static_cast<uint64_t>(i) * width;
+        for (int j = 0; j < beam_count[i]; ++j) beam.push(bd[j], static_cast<node_id_t>(bi[j]));
+        pruneNeighbors(beam, keep, *scratch);
+        node_id_t mine[1 + 64];
+        int n_mine = 0;
+        const node_id_t new_id = static_cast<node_id_t>(cur + i);
+        mine[n_mine++] = new_id;
+        for (int j = 0; j < beam.size() && n_mine < 65; ++j) mine[n_mine++] = beam.a.items[static_cast<size_t>(j)].val;
+        linkNeighbors(beam, new_id, *scratch);
+        returnScratch(std::move(scratch));
+        std::lock_guard<std::mutex> g(touched_guard);
+        touched.insert(touched.end(), mine, mine + n_mine);
+      };
+      if (_num_threads == 1) for (uint32_t i = 0; i < batch; ++i) wire(i);
+      else flatnav::executeInParallel(0, static_cast<uint32_t>(batch), _num_threads, wire);
+      if (_collect_stats) {
+        uint64_t evals = batch * static_cast<uint64_t>(num_initializations);
+        for (uint64_t e : beam_evals) evals += e;
+        _distance_computations.fetch_add(evals);
+      }
+      // 4. mirror every link row that changed, then let searches see the batch
+      std::sort(touched.begin(), touched.end());
+      touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+      link_rows.resize(touched.size() * _M);
+      auto packRow = [&](uint32_t t) { std::memcpy(link_rows.data() + static_cast<uint64_t>(t) * _M, nodeLinks(touched[t]), _M * sizeof(node_id_t)); };
+      if (_num_threads == 1) for (uint32_t t = 0; t < touched.size(); ++t) packRow(t);
+      else flatnav::executeInParallel(0, static_cast<uint32_t>(touched.size()), _num_threads, packRow);
+      detail::throwOnDeviceError(fnv_index_write_links(_device_index, touched.data(), link_rows.data(), touched.size()));
+      detail::throwOnDeviceError(fnv_index_set_live_nodes(_device_index, cur + batch));
+      row += batch;
+    }
+    _device_stale = false;  // the device copy was kept in step
   }
 
   void add(void* data, label_t& label, int ef_construction, int num_initializations) {

@@ -93,6 +93,25 @@ int fnv_index_info(fnv_index_t index, uint64_t info[8]);
 
 int fnv_index_free(fnv_index_t index);
 
+/* ---- incremental construction --------------------------------------------------
+ * The reference inserts a point by running the SAME beam search over the nodes present so far
+ * (Index::add, include/flatnav/index/Index.h:353-378: initializeSearch + beamSearch with
+ * ef_construction), then selectNeighbors / connectNeighbors (:714-834).  These three calls let a
+ * host builder keep a device index in step with its node store so that the beam searches of a
+ * whole batch of insertions run as one fnv_search_batch launch:
+ *   - allocate at full capacity (fnv_index_alloc), searches see only nodes [0, n_live);
+ *   - fnv_index_write_nodes copies AoS node records first..first+count-1 (same layout as
+ *     fnv_index_upload) into the device buffers;
+ *   - fnv_index_write_links overwrites the link rows (M ids each) of `count` scattered nodes after
+ *     the host has wired a batch.
+ * With option "output_node_ids" = 1 searches return node ids instead of labels.
+ * Callers must not run these concurrently with a search on the same handle. */
+int fnv_index_set_live_nodes(fnv_index_t index, uint64_t n_live);
+int fnv_index_write_nodes(fnv_index_t index, uint64_t first_node, uint64_t count, const void* aos_rows,
+                          uint64_t node_size_bytes, uint64_t data_size_bytes);
+int fnv_index_write_links(fnv_index_t index, const uint32_t* node_ids, const uint32_t* link_rows,
+                          uint64_t count);
+
 /* Tuning / test knobs (all optional).  Names:
  *   "visited_factor"  roomy LDS visited-table size = visited_factor * beam width + 600 slots, rounded up to
  *                     2^j or 3*2^j (default 27); used as is while "occupancy_target" queries fit per CU
@@ -105,6 +124,7 @@ int fnv_index_free(fnv_index_t index);
  *   "cand_slots"      force the LDS candidate-heap capacity (0 = from factor)
  *   "spill_entries"   per-slot HBM spill capacity of the candidate heap (default 16384)
  *   "blocks_per_cu"   cap resident query slots per CU (0 = occupancy limit)
+ *   "output_node_ids" 1 = out_labels receives node ids, not labels (used by the device-assisted builder)
  *   "entry_kernel"    1 = entry points of the whole batch come from the LDS-staged entry_scan_kernel (K0);
  *                     0 (default) = every query scans them inside the search kernel.  Same results bit for
  *                     bit; measured equally fast on MI355X (the shared scan rows are L2 hits either way)

@@ -1,0 +1,123 @@
+"""Device-assisted construction: index.add(..., device=True) runs the insertions' beam searches
+on the GPU in batches (reference insertion rule: Index.h:353-378 + selectNeighbors/connectNeighbors :714-834).
+The graph is of the same family, not byte-identical (neither is the reference's own multi-threaded build), so
+the checks are: structural validity, search quality equal to the host builder's, and -- the part that must be
+exact -- the incrementally maintained device copy answering exactly like the CPU oracle on the host blob."""
+import numpy as np
+import pytest
+
+from flatnav_amd import datasets as ds, hip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def flatnav():
+    import flatnav_amd
+
+    return flatnav_amd
+
+
+def _links(index, n, node_size, data_size, M):
+    blob = np.asarray(index._raw_blob())[: n * node_size].reshape(n, node_size)
+    return blob[:, data_size:data_size + 4 * M].copy().view(np.uint32)
+
+
+def _check_graph(index, n, M):
+    L = _links(index, n, index._node_size_bytes, index._data_size_bytes, M)
+    assert (L < n).all()
+    own = np.arange(n, dtype=np.uint32)[:, None]
+    real = L != own
+    assert real[1:].any(axis=1).all()  # every node but possibly the first is wired to something
+    srt = np.sort(np.where(real, L, np.uint32(0xFFFFFFFF)), axis=1)
+    dup = (srt[:, 1:] == srt[:, :-1]) & (srt[:, 1:] != 0xFFFFFFFF)
+    assert not dup.any()  # no repeated neighbour in a row
+    return real.sum(axis=1).mean()
+
+
+@pytest.mark.parametrize("dt", ["float32", "uint8"])
+def test_device_build_matches_host_build_quality(flatnav, oracle_mod, dt):
+    N, NQ, M, K = 20000, 500, 32, 10
+    X, Q = ds.sift_like(N, NQ)
+    X, Q = X.astype(dt), Q.astype(dt)
+    gt = ds.exact_topk_l2(X.astype(np.float32), Q.astype(np.float32), K)
+    DT = getattr(flatnav.data_type.DataType, dt)
+    host = flatnav.index.create("l2", 128, N, M, DT)
+    host.set_num_threads(4)
+    host.add(X, 100)
+    dev = flatnav.index.create("l2", 128, N, M, DT, collect_stats=True)
+    dev.set_num_threads(4)
+    dev.add(X, 100, device=True, device_max_batch=2048)
+    assert dev._cur_num_nodes == N
+    deg = _check_graph(dev, N, M)
+    assert deg > 0.9 * _check_graph(host, N, M)
+    assert dev.get_query_distance_computations() > N * 100  # insertions are counted like the reference counts them
+    for ef in (50, 100):
+        _, lh = host.search(Q, K, ef)
+        dd, ld = dev.search(Q, K, ef)  # answered by the device copy that was maintained batch by batch
+        assert ds.recall_at_k(ld, gt) > ds.recall_at_k(lh, gt) - 0.01
+        o = oracle_mod.OracleIndex.from_blob("l2", dt, 128, N, N, M, np.asarray(dev._raw_blob()))
+        od, ol = o.search(Q, K, ef)
+        assert (ol == ld).all() and (od == dd).all()
+
+
+def test_device_build_appends_to_an_existing_graph(flatnav, oracle_mod):
+    N, NQ, M, K = 12000, 300, 16, 10
+    X, Q = ds.lowrank_normalized(N, NQ, 100, 24, 5)
+    ix = flatnav.index.create("angular", 100, N, M, flatnav.data_type.DataType.float32)
+    ix.set_num_threads(4)
+    ix.add(X[:5000], 64, labels=list(range(100000, 105000)))
+    ix.search(Q, K, 64)  # uploads the 5000-node graph: the builder must replace that device copy
+    ix.add(X[5000:], 64, labels=list(range(200000, 200000 + N - 5000)), device=True)
+    assert ix._cur_num_nodes == N
+    _check_graph(ix, N, M)
+    d, l = ix.search(Q, K, 100)
+    gt = ds.exact_topk_ip(X, Q, K)
+    lab = np.concatenate([np.arange(100000, 105000), np.arange(200000, 200000 + N - 5000)])
+    assert ds.recall_at_k(l, lab[gt]) > 0.9
+    o = oracle_mod.OracleIndex.from_blob("angular", "float32", 100, N, N, M, np.asarray(ix._raw_blob()))
+    od, ol = o.search(Q, K, 100)
+    assert (ol == l).all(axis=1).mean() > 0.99  # float: rare rounding flips allowed, as in the other parity tests
+    # a later host insertion invalidates the device copy again and still works
+    with pytest.raises(RuntimeError):
+        ix.add(X[:1], 64, device=True)  # full
+    with pytest.raises(ValueError):
+        flatnav.index.create("l2", 100, 10, M).add(X[:5], 64, 0, device=True)
+
+
+def test_c_abi_incremental_writes_equal_one_upload(oracle_mod):
+    N, NQ, M, K = 8000, 400, 16, 10
+    X, Q = ds.sift_like(N, NQ)
+    o = oracle_mod.OracleIndex.create("l2", 128, N, M, "float32")
+    o.add(X[: N // 2], 64)
+    blob = np.asarray(o.blob())
+    node_size, data_size = 128 * 4 + 4 * M + 4, 128 * 4
+    half = N // 2
+    whole = hip.DeviceIndex.upload(blob, node_size, data_size, M, half, "float32", "l2", 128)
+    inc = hip.DeviceIndex.alloc(M, N, "float32", "l2", 128)  # room for N, holds N/2
+    cut = 1234
+    inc.write_nodes(0, blob[: cut * node_size], node_size, data_size)
+    inc.write_nodes(cut, blob[cut * node_size: half * node_size], node_size, data_size)
+    inc.set_live_nodes(half)
+    dw, lw = whole.search(Q, K, 80)
+    di, li = inc.search(Q, K, 80)
+    assert (lw == li).all() and (dw == di).all()
+    # rewrite some link rows: point node 7's row at 1..M, search must follow the new row like a fresh upload does
+    rows = blob[: half * node_size].reshape(half, node_size).copy()
+    new_row = np.arange(1, M + 1, dtype=np.uint32)
+    rows[7, data_size:data_size + 4 * M] = new_row.view(np.uint8)
+    inc.write_links(np.array([7], dtype=np.uint32), new_row[None, :])
+    whole2 = hip.DeviceIndex.upload(rows.reshape(-1), node_size, data_size, M, half, "float32", "l2", 128)
+    d2, l2 = whole2.search(Q, K, 80)
+    di, li = inc.search(Q, K, 80)
+    assert (l2 == li).all() and (d2 == di).all()
+    inc.set_option("output_node_ids", 1)
+    _, ids = inc.search(Q, K, 80)
+    labels = rows[:, data_size + 4 * M:].copy().view(np.int32).reshape(-1)
+    assert (labels[ids] == li).all()
+    with pytest.raises(ValueError):
+        inc.set_live_nodes(N + 1)
+    with pytest.raises(RuntimeError):
+        inc.write_nodes(N - 1, blob[: 2 * node_size], node_size, data_size)  # past capacity
+    with pytest.raises(RuntimeError):
+        inc.write_links(np.array([3], dtype=np.uint32), np.full((1, M), N + 5, dtype=np.uint32))  # id out of range
