@@ -33,6 +33,7 @@
 
 #include "../../include/flatnav_hip.h"
 #include "kernels.hpp"
+#include "wire.hpp"
 
 using namespace fnv_dev;
 
@@ -115,6 +116,33 @@ kernel_fn pick_kernel(int dtype, int metric, int cfg, bool full) {
   return pick_metric<int8_t>(metric, cfg, full);
 }
 
+typedef void (*wire_fn)(const WireParams);
+
+template <typename T, int METRIC, bool FULL>
+wire_fn pick_wire_cfg(int c) {
+  switch (c) {
+    case 0: return wire_batch_kernel<T, METRIC, 8, 1, FULL>;
+    case 1: return wire_batch_kernel<T, METRIC, 8, 2, FULL>;
+    case 2: return wire_batch_kernel<T, METRIC, 8, 4, FULL>;
+    case 3: return wire_batch_kernel<T, METRIC, 16, 4, FULL>;
+    case 4: return wire_batch_kernel<T, METRIC, 32, 4, FULL>;
+    default: return wire_batch_kernel<T, METRIC, 64, 4, FULL>;
+  }
+}
+
+template <typename T>
+wire_fn pick_wire_metric(int metric, int cfg, bool full) {
+  if (metric == FNV_METRIC_L2)
+    return full ? pick_wire_cfg<T, FNV_METRIC_L2, true>(cfg) : pick_wire_cfg<T, FNV_METRIC_L2, false>(cfg);
+  return full ? pick_wire_cfg<T, FNV_METRIC_IP, true>(cfg) : pick_wire_cfg<T, FNV_METRIC_IP, false>(cfg);
+}
+
+wire_fn pick_wire_kernel(int dtype, int metric, int cfg, bool full) {
+  if (dtype == FNV_DTYPE_FLOAT32) return pick_wire_metric<float>(metric, cfg, full);
+  if (dtype == FNV_DTYPE_UINT8) return pick_wire_metric<uint8_t>(metric, cfg, full);
+  return pick_wire_metric<int8_t>(metric, cfg, full);
+}
+
 }  // namespace
 
 struct fnv_index_s {
@@ -138,6 +166,7 @@ struct fnv_index_s {
   size_t entry_bytes = 0;
   uint32_t* d_bitmap = nullptr;
   size_t bitmap_bytes = 0;
+  uint32_t* d_locks = nullptr;  // fnv_index_insert_batch: one spin lock per node (all zero between launches)
   void* d_linkstage = nullptr;  // fnv_index_write_links: [count] ids | [count][M] rows | bad flag
   size_t linkstage_bytes = 0;
   unsigned long long* d_spill = nullptr;
@@ -336,7 +365,7 @@ int fnv_index_free(fnv_index_t ix) {
   if (!ix) return FNV_OK;
   (void)hipSetDevice(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_bitmap, ix->d_linkstage, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase, ix->d_entry};
+  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_bitmap, ix->d_linkstage, ix->d_locks, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase, ix->d_entry};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (ix->ev0) (void)hipEventDestroy(ix->ev0);
@@ -691,6 +720,143 @@ int fnv_search_batch(fnv_index_t ix, const void* queries, uint64_t nq, int K, in
   if (out_nhops) HIP_TRY(hipMemcpyAsync(out_nhops, o + o_nh, (size_t)nq * 8, hipMemcpyDeviceToHost, ix->stream));
   HIP_TRY(hipStreamSynchronize(ix->stream));
   return fnv_search_status(ix);
+}
+
+int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, int ef_construction,
+                           int num_initializations, uint64_t* evals_out) {
+  if (!ix) return fail(FNV_ERR_INVALID, "index is null");
+  if (num_initializations <= 0) return fail(FNV_ERR_INVALID, "num_initializations must be greater than 0.");
+  if (ef_construction <= 0) return fail(FNV_ERR_INVALID, "ef_construction must be positive");
+  if (ix->M > (uint32_t)WAVE) return fail(FNV_ERR_INVALID, "device-side wiring supports max_edges_per_node <= 64");
+  if (first_node != ix->n_nodes || first_node == 0)
+    return fail(FNV_ERR_INVALID, "insert_batch: first_node must equal the live node count (and the graph be non-empty)");
+  if (count > ix->capacity - first_node)
+    return fail(FNV_ERR_RUNTIME, "Maximum number of nodes reached. (device index capacity)");
+  if (evals_out) *evals_out = 0;
+  if (count == 0) return FNV_OK;
+  std::lock_guard<std::mutex> host_lock(ix->host_mu);
+  HIP_TRY(hipSetDevice(ix->device));
+  const int W = ef_construction;
+  const size_t esize = dtype_size(ix->dtype);
+  const size_t qrow = (size_t)ix->dim * esize;
+  const size_t qbytes = count * qrow;
+  const size_t o_dist = 0;
+  const size_t o_lab = o_dist + (size_t)count * W * 4;
+  const size_t o_cnt = o_lab + (size_t)count * W * 4;
+  const size_t o_nd = (o_cnt + (size_t)count * 4 + 7) & ~(size_t)7;
+  const size_t obytes = o_nd + (size_t)count * 8;
+  {
+    std::lock_guard<std::mutex> lock(ix->mu);
+    if (qbytes > ix->d_q_bytes) {
+      if (ix->d_q) HIP_TRY(hipFree(ix->d_q));
+      ix->d_q = nullptr;
+      ix->d_q_bytes = 0;
+      HIP_TRY(hipMalloc(&ix->d_q, qbytes));
+      ix->d_q_bytes = qbytes;
+    }
+    if (obytes > ix->d_out_bytes) {
+      if (ix->d_out) HIP_TRY(hipFree(ix->d_out));
+      ix->d_out = nullptr;
+      ix->d_out_bytes = 0;
+      HIP_TRY(hipMalloc(&ix->d_out, obytes));
+      ix->d_out_bytes = obytes;
+    }
+    if (!ix->d_locks) {
+      HIP_TRY(hipMalloc(&ix->d_locks, ix->capacity * 4));
+      HIP_TRY(hipMemset(ix->d_locks, 0, ix->capacity * 4));
+    }
+  }
+  uint8_t* o = (uint8_t*)ix->d_out;
+  // the new nodes' vectors are the queries (Index.h:371: beamSearch(data, entry, ef_construction)); dense rows
+  HIP_TRY(hipMemcpy2DAsync(ix->d_q, qrow, ix->d_vectors + first_node * (uint64_t)ix->row_bytes, ix->row_bytes, qrow,
+                           count, hipMemcpyDeviceToDevice, ix->stream));
+  const int64_t saved = ix->output_node_ids;
+  ix->output_node_ids = 1;
+  int rc = fnv_search_batch_device(ix, ix->d_q, count, W, W, num_initializations, (float*)(o + o_dist),
+                                   (int32_t*)(o + o_lab), (int32_t*)(o + o_cnt), (uint64_t*)(o + o_nd), nullptr,
+                                   ix->stream);
+  ix->output_node_ids = saved;
+  if (rc) return rc;
+
+  std::lock_guard<std::mutex> lock(ix->mu);
+  WireParams w;
+  memset(&w, 0, sizeof(w));
+  w.vectors = ix->d_vectors;
+  w.links = ix->d_links;
+  w.locks = ix->d_locks;
+  w.beam_dist = (const float*)(o + o_dist);
+  w.beam_ids = (const int32_t*)(o + o_lab);
+  w.beam_count = (const int32_t*)(o + o_cnt);
+  w.dispenser = ix->d_dispenser;
+  w.first_node = (uint32_t)first_node;
+  w.count = (uint32_t)count;
+  w.W = (uint32_t)W;
+  w.M = ix->M;
+  w.keep = std::max<uint32_t>(ix->M / 2, 1);  // Index.h:373
+  w.row_bytes = ix->row_bytes;
+  w.nchunks = ix->row_bytes / 16;
+  int cfg = kNumCfgs - 1;
+  for (int c = 0; c < kNumCfgs; c++)
+    if ((uint32_t)(kCfgs[c].G * kCfgs[c].CU) >= w.nchunks) {
+      cfg = c;
+      break;
+    }
+  const uint32_t per_iter = (uint32_t)(kCfgs[cfg].G * kCfgs[cfg].CU);
+  w.q_chunks = (w.nchunks + per_iter - 1) / per_iter * per_iter;
+  const bool full = (w.nchunks % per_iter) == 0;
+  w.cap = std::max<uint32_t>((uint32_t)W, ix->M + 1);
+  auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+  uint32_t off = 0;
+  w.off_q = off;
+  off = align16(off + w.q_chunks * 16);
+  uint32_t* offs[] = {&w.off_ckey, &w.off_cid, &w.off_okey, &w.off_oid, &w.off_alive, &w.off_kept, &w.off_sel};
+  for (uint32_t* f : offs) {
+    *f = off;
+    off = align16(off + w.cap * 4);
+  }
+  w.off_stage_ids = off;
+  off = align16(off + (WAVE + 1) * 4);
+  w.off_stage_idx = off;
+  off = align16(off + (WAVE + 1) * 4);
+  const uint32_t lds_bytes = off;
+  if (lds_bytes > 160u * 1024u) return fail(FNV_ERR_INVALID, "ef_construction too large for the on-chip wiring state");
+  wire_fn kern = pick_wire_kernel(ix->dtype, ix->metric, cfg, full);
+  HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  int bpc = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, WAVE, lds_bytes));
+  if (bpc < 1) bpc = 1;
+  const uint32_t nslots = (uint32_t)std::min<uint64_t>(count, (uint64_t)bpc * (uint64_t)ix->num_cus);
+  HIP_TRY(hipMemsetAsync(ix->d_dispenser, 0, sizeof(uint32_t), ix->stream));
+  hipLaunchKernelGGL(kern, dim3(nslots), dim3(WAVE), lds_bytes, ix->stream, w);
+  HIP_TRY(hipGetLastError());
+  std::vector<uint64_t> nd;
+  if (evals_out) {
+    nd.resize(count);
+    HIP_TRY(hipMemcpyAsync(nd.data(), o + o_nd, count * 8, hipMemcpyDeviceToHost, ix->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  if (evals_out) {
+    uint64_t total = 0;
+    for (uint64_t e : nd) total += e;
+    *evals_out = total;
+  }
+  int32_t st = 0;
+  HIP_TRY(hipMemcpy(&st, ix->d_dispenser + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (st == ST_CAND_OVERFLOW)
+    return fail(FNV_ERR_CAPACITY, "candidate heap overflowed its HBM spill area; raise spill_entries");
+  ix->n_nodes = first_node + count;
+  return FNV_OK;
+}
+
+int fnv_index_read_links(fnv_index_t ix, uint64_t first_node, uint64_t count, uint32_t* out_rows) {
+  if (!ix || (!out_rows && count)) return fail(FNV_ERR_INVALID, "null argument");
+  if (first_node > ix->capacity || count > ix->capacity - first_node)
+    return fail(FNV_ERR_INVALID, "node range outside the device index");
+  if (count == 0) return FNV_OK;
+  std::lock_guard<std::mutex> lock(ix->mu);
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(hipMemcpy(out_rows, ix->d_links + first_node * (uint64_t)ix->M, count * 4ull * ix->M, hipMemcpyDeviceToHost));
+  return FNV_OK;
 }
 
 int fnv_last_kernel_ms(fnv_index_t ix, float* ms) {

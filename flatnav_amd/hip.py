@@ -23,7 +23,8 @@ C_ABI_SYMBOLS = [
     "fnv_last_error", "fnv_version", "fnv_device_count", "fnv_index_upload", "fnv_index_alloc",
     "fnv_index_device_buffers", "fnv_index_info", "fnv_index_free", "fnv_set_option", "fnv_search_batch",
     "fnv_search_batch_device", "fnv_search_status", "fnv_last_kernel_ms", "fnv_last_launch_geometry",
-    "fnv_index_set_live_nodes", "fnv_index_write_nodes", "fnv_index_write_links",
+    "fnv_index_set_live_nodes", "fnv_index_write_nodes", "fnv_index_write_links", "fnv_index_insert_batch",
+    "fnv_index_read_links",
 ]
 
 _lib = None
@@ -59,6 +60,8 @@ def lib() -> C.CDLL:
     L.fnv_index_set_live_nodes.argtypes = [C.c_void_p, C.c_uint64]
     L.fnv_index_write_nodes.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]
     L.fnv_index_write_links.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.fnv_index_insert_batch.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+    L.fnv_index_read_links.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
     L.fnv_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.fnv_search_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
     L.fnv_search_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int] + [
@@ -159,6 +162,19 @@ class DeviceIndex:
         ids = np.ascontiguousarray(node_ids, dtype=np.uint32).reshape(-1)
         rows = np.ascontiguousarray(link_rows, dtype=np.uint32).reshape(ids.size, self.M)
         check(lib().fnv_index_write_links(self._h, ids.ctypes.data, rows.ctypes.data, ids.size))
+
+    def insert_batch(self, first_node: int, count: int, ef_construction: int, num_initializations: int = 100) -> int:
+        """Search + wire nodes [first_node, first_node+count) on the device; returns the distance evaluations."""
+        ev = C.c_uint64(0)
+        check(lib().fnv_index_insert_batch(self._h, int(first_node), int(count), int(ef_construction),
+                                           int(num_initializations), C.byref(ev)))
+        self.n_nodes = int(first_node) + int(count)
+        return int(ev.value)
+
+    def read_links(self, first_node: int, count: int) -> np.ndarray:
+        out = np.empty((int(count), self.M), dtype=np.uint32)
+        check(lib().fnv_index_read_links(self._h, int(first_node), int(count), out.ctypes.data))
+        return out
 
     def set_option(self, name: str, value: int) -> None:
         check(lib().fnv_set_option(self._h, name.encode(), int(value)))

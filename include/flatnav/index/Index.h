@@ -484,6 +484,7 @@ class Index {
     uint32_t max_batch = 32768;
     uint32_t bootstrap = 2048;
     uint32_t growth_divisor = 4;
+    bool wire_on_device = true;  // pruning + back-links by wire_batch_kernel (M <= 64); false: on the host threads
   };
 
   template <typename data_type>
@@ -519,6 +520,8 @@ class Index {
       ~RestoreLabels() { fnv_set_option(ix, "output_node_ids", 0); }
     } restore{_device_index};
 
+    const bool device_wiring = opt.wire_on_device && _M <= 64;
+    const uint64_t first_device_node = _cur_num_nodes;
     const int width = ef_construction;
     const int keep = std::max(static_cast<int>(_M / 2), 1);
     std::vector<float> beam_dist;
@@ -538,6 +541,14 @@ class Index {
       }
       detail::throwOnDeviceError(fnv_index_write_nodes(_device_index, cur, batch, nodeData(static_cast<node_id_t>(cur)),
                                                        _node_size_bytes, _data_size_bytes));
+      if (device_wiring) {  // search + prune + wire in HBM; the host rows are refreshed once at the end
+        uint64_t evals = 0;
+        detail::throwOnDeviceError(
+            fnv_index_insert_batch(_device_index, cur, batch, width, num_initializations, &evals));
+        if (_collect_stats) _distance_computations.fetch_add(evals + batch * static_cast<uint64_t>(num_initializations));
+        row += batch;
+        continue;
+      }
       // 2. the beam searches of the batch: one launch, full beams back (node ids, ascending distance)
       beam_dist.resize(batch * width);
       beam_ids.resize(batch * width);
@@ -583,6 +594,14 @@ class Index {
       detail::throwOnDeviceError(fnv_index_write_links(_device_index, touched.data(), link_rows.data(), touched.size()));
       detail::throwOnDeviceError(fnv_index_set_live_nodes(_device_index, cur + batch));
       row += batch;
+    }
+    if (device_wiring) {  // bring every link row home (old nodes gained back-links too)
+      (void)first_device_node;
+      link_rows.resize(_cur_num_nodes * _M);
+      detail::throwOnDeviceError(fnv_index_read_links(_device_index, 0, _cur_num_nodes, link_rows.data()));
+      auto unpackRow = [&](uint32_t n) { std::memcpy(nodeLinks(n), link_rows.data() + static_cast<uint64_t>(n) * _M, _M * sizeof(node_id_t)); };
+      if (_num_threads == 1) for (uint32_t n = 0; n < _cur_num_nodes; ++n) unpackRow(n);
+      else flatnav::executeInParallel(0, static_cast<uint32_t>(_cur_num_nodes), _num_threads, unpackRow);
     }
     _device_stale = false;  // the device copy was kept in step
   }

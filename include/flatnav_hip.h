@@ -112,6 +112,17 @@ int fnv_index_write_nodes(fnv_index_t index, uint64_t first_node, uint64_t count
 int fnv_index_write_links(fnv_index_t index, const uint32_t* node_ids, const uint32_t* link_rows,
                           uint64_t count);
 
+/* Whole insertions on the device: nodes first_node..first_node+count-1 (records already written with
+ * fnv_index_write_nodes, first_node == live count) are searched for with beam width ef_construction
+ * against the live graph (Index.h:367-371), then wired by wire_batch_kernel: selectNeighbors to M/2
+ * (Index.h:714-763), own row, back-links with re-pruning under per-node locks (connectNeighbors,
+ * Index.h:765-834).  On return the batch is live.  evals_out (nullable) receives the distance
+ * evaluations of the beam searches (what the reference adds to its counter, Index.h:689-691).
+ * max_edges_per_node <= 64.  fnv_index_read_links copies link rows back for the host node store. */
+int fnv_index_insert_batch(fnv_index_t index, uint64_t first_node, uint64_t count, int ef_construction,
+                           int num_initializations, uint64_t* evals_out);
+int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count, uint32_t* out_rows);
+
 /* Tuning / test knobs (all optional).  Names:
  *   "visited_factor"  roomy LDS visited-table size = visited_factor * beam width + 600 slots, rounded up to
  *                     2^j or 3*2^j (default 27); used as is while "occupancy_target" queries fit per CU

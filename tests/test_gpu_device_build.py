@@ -35,8 +35,9 @@ def _check_graph(index, n, M):
     return real.sum(axis=1).mean()
 
 
+@pytest.mark.parametrize("wiring", [True, False], ids=["device_wiring", "host_wiring"])
 @pytest.mark.parametrize("dt", ["float32", "uint8"])
-def test_device_build_matches_host_build_quality(flatnav, oracle_mod, dt):
+def test_device_build_matches_host_build_quality(flatnav, oracle_mod, dt, wiring):
     N, NQ, M, K = 20000, 500, 32, 10
     X, Q = ds.sift_like(N, NQ)
     X, Q = X.astype(dt), Q.astype(dt)
@@ -47,7 +48,7 @@ def test_device_build_matches_host_build_quality(flatnav, oracle_mod, dt):
     host.add(X, 100)
     dev = flatnav.index.create("l2", 128, N, M, DT, collect_stats=True)
     dev.set_num_threads(4)
-    dev.add(X, 100, device=True, device_max_batch=2048)
+    dev.add(X, 100, device=True, device_max_batch=2048, device_wiring=wiring)
     assert dev._cur_num_nodes == N
     deg = _check_graph(dev, N, M)
     assert deg > 0.9 * _check_graph(host, N, M)

@@ -30,10 +30,10 @@ def report(tag, ix):
         ix.get_query_distance_computations()
         t0 = time.perf_counter(); d, l = ix.search(Q, K, ef); dt = time.perf_counter() - t0
         evals = ix.get_query_distance_computations() / NQ
-        print("%-22s ef=%3d: recall@10 %.4f  evals/q %.0f  %.0f QPS (host buffers)" %
+        print("%-40s ef=%3d: recall@10 %.4f  evals/q %.0f  %.0f QPS (host buffers)" %
               (tag, ef, ds.recall_at_k(l[:1000], gt), evals, NQ / dt), flush=True)
     tab = ix.get_graph_outdegree_table()
-    print("%-22s mean out-degree %.2f" % (tag, float(np.mean([len(r) for r in tab[:100000]]))), flush=True)
+    print("%-40s mean out-degree %.2f" % (tag, float(np.mean([len(r) for r in tab[:100000]]))), flush=True)
 
 
 if not args.skip_host:
@@ -42,8 +42,10 @@ if not args.skip_host:
     t0 = time.time(); ix.add(X, args.efc); print("host builder (%d threads): %.1fs" % (threads, time.time() - t0), flush=True)
     report("host", ix); del ix
 for mb in [int(b) for b in args.max_batch.split(",")]:
+  for wiring in (True, False):
     ix = flatnav.index.create(metric, args.dim, args.n, M, flatnav.data_type.DataType.float32, collect_stats=True)
     ix.set_num_threads(threads)
-    t0 = time.time(); ix.add(X, args.efc, device=True, device_max_batch=mb)
-    print("device-assisted builder (max batch %d, %d host threads): %.1fs" % (mb, threads, time.time() - t0), flush=True)
-    report("device b=%d" % mb, ix); del ix
+    t0 = time.time(); ix.add(X, args.efc, device=True, device_max_batch=mb, device_wiring=wiring)
+    tag = "device search + %s wiring, b=%d" % ("device" if wiring else "host", mb)
+    print("%s (%d host threads): %.2fs" % (tag, threads, time.time() - t0), flush=True)
+    report(tag, ix); del ix
