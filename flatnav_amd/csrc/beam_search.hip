@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -121,12 +122,12 @@ typedef void (*wire_fn)(const WireParams);
 template <typename T, int METRIC, bool FULL>
 wire_fn pick_wire_cfg(int c) {
   switch (c) {
-    case 0: return wire_batch_kernel<T, METRIC, 8, 1, FULL>;
-    case 1: return wire_batch_kernel<T, METRIC, 8, 2, FULL>;
-    case 2: return wire_batch_kernel<T, METRIC, 8, 4, FULL>;
-    case 3: return wire_batch_kernel<T, METRIC, 16, 4, FULL>;
-    case 4: return wire_batch_kernel<T, METRIC, 32, 4, FULL>;
-    default: return wire_batch_kernel<T, METRIC, 64, 4, FULL>;
+    case 0: return wire_select_kernel<T, METRIC, 8, 1, FULL>;
+    case 1: return wire_select_kernel<T, METRIC, 8, 2, FULL>;
+    case 2: return wire_select_kernel<T, METRIC, 8, 4, FULL>;
+    case 3: return wire_select_kernel<T, METRIC, 16, 4, FULL>;
+    case 4: return wire_select_kernel<T, METRIC, 32, 4, FULL>;
+    default: return wire_select_kernel<T, METRIC, 64, 4, FULL>;
   }
 }
 
@@ -141,6 +142,31 @@ wire_fn pick_wire_kernel(int dtype, int metric, int cfg, bool full) {
   if (dtype == FNV_DTYPE_FLOAT32) return pick_wire_metric<float>(metric, cfg, full);
   if (dtype == FNV_DTYPE_UINT8) return pick_wire_metric<uint8_t>(metric, cfg, full);
   return pick_wire_metric<int8_t>(metric, cfg, full);
+}
+
+template <typename T, int METRIC, bool FULL>
+wire_fn pick_connect_cfg(int c) {
+  switch (c) {
+    case 0: return wire_connect_kernel<T, METRIC, 8, 1, FULL>;
+    case 1: return wire_connect_kernel<T, METRIC, 8, 2, FULL>;
+    case 2: return wire_connect_kernel<T, METRIC, 8, 4, FULL>;
+    case 3: return wire_connect_kernel<T, METRIC, 16, 4, FULL>;
+    case 4: return wire_connect_kernel<T, METRIC, 32, 4, FULL>;
+    default: return wire_connect_kernel<T, METRIC, 64, 4, FULL>;
+  }
+}
+
+template <typename T>
+wire_fn pick_connect_metric(int metric, int cfg, bool full) {
+  if (metric == FNV_METRIC_L2)
+    return full ? pick_connect_cfg<T, FNV_METRIC_L2, true>(cfg) : pick_connect_cfg<T, FNV_METRIC_L2, false>(cfg);
+  return full ? pick_connect_cfg<T, FNV_METRIC_IP, true>(cfg) : pick_connect_cfg<T, FNV_METRIC_IP, false>(cfg);
+}
+
+wire_fn pick_connect_kernel(int dtype, int metric, int cfg, bool full) {
+  if (dtype == FNV_DTYPE_FLOAT32) return pick_connect_metric<float>(metric, cfg, full);
+  if (dtype == FNV_DTYPE_UINT8) return pick_connect_metric<uint8_t>(metric, cfg, full);
+  return pick_connect_metric<int8_t>(metric, cfg, full);
 }
 
 }  // namespace
@@ -166,7 +192,9 @@ struct fnv_index_s {
   size_t entry_bytes = 0;
   uint32_t* d_bitmap = nullptr;
   size_t bitmap_bytes = 0;
-  uint32_t* d_locks = nullptr;  // fnv_index_insert_batch: one spin lock per node (all zero between launches)
+  int32_t* d_head = nullptr;     // fnv_index_insert_batch: per-node request list heads (all -1 between launches)
+  void* d_wirebuf = nullptr;     // [16 B: n_targets] [count*keep] req_next [count*keep] targets
+  size_t wirebuf_bytes = 0;
   void* d_linkstage = nullptr;  // fnv_index_write_links: [count] ids | [count][M] rows | bad flag
   size_t linkstage_bytes = 0;
   unsigned long long* d_spill = nullptr;
@@ -365,7 +393,7 @@ int fnv_index_free(fnv_index_t ix) {
   if (!ix) return FNV_OK;
   (void)hipSetDevice(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_bitmap, ix->d_linkstage, ix->d_locks, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase, ix->d_entry};
+  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_bitmap, ix->d_linkstage, ix->d_head, ix->d_wirebuf, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase, ix->d_entry};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (ix->ev0) (void)hipEventDestroy(ix->ev0);
@@ -737,6 +765,7 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
   std::lock_guard<std::mutex> host_lock(ix->host_mu);
   HIP_TRY(hipSetDevice(ix->device));
   const int W = ef_construction;
+  const uint32_t keep = std::max<uint32_t>(ix->M / 2, 1);  // Index.h:373
   const size_t esize = dtype_size(ix->dtype);
   const size_t qrow = (size_t)ix->dim * esize;
   const size_t qbytes = count * qrow;
@@ -761,9 +790,17 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
       HIP_TRY(hipMalloc(&ix->d_out, obytes));
       ix->d_out_bytes = obytes;
     }
-    if (!ix->d_locks) {
-      HIP_TRY(hipMalloc(&ix->d_locks, ix->capacity * 4));
-      HIP_TRY(hipMemset(ix->d_locks, 0, ix->capacity * 4));
+    if (!ix->d_head) {
+      HIP_TRY(hipMalloc(&ix->d_head, ix->capacity * 4));
+      HIP_TRY(hipMemset(ix->d_head, 0xFF, ix->capacity * 4));
+    }
+    const size_t wb = 16 + 2 * count * (size_t)keep * 4;
+    if (wb > ix->wirebuf_bytes) {
+      if (ix->d_wirebuf) HIP_TRY(hipFree(ix->d_wirebuf));
+      ix->d_wirebuf = nullptr;
+      ix->wirebuf_bytes = 0;
+      HIP_TRY(hipMalloc(&ix->d_wirebuf, wb));
+      ix->wirebuf_bytes = wb;
     }
   }
   uint8_t* o = (uint8_t*)ix->d_out;
@@ -783,7 +820,10 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
   memset(&w, 0, sizeof(w));
   w.vectors = ix->d_vectors;
   w.links = ix->d_links;
-  w.locks = ix->d_locks;
+  w.head = ix->d_head;
+  w.n_targets = (uint32_t*)ix->d_wirebuf;
+  w.req_next = (int32_t*)((uint8_t*)ix->d_wirebuf + 16);
+  w.targets = (uint32_t*)(w.req_next + count * (size_t)keep);
   w.beam_dist = (const float*)(o + o_dist);
   w.beam_ids = (const int32_t*)(o + o_lab);
   w.beam_count = (const int32_t*)(o + o_cnt);
@@ -792,7 +832,7 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
   w.count = (uint32_t)count;
   w.W = (uint32_t)W;
   w.M = ix->M;
-  w.keep = std::max<uint32_t>(ix->M / 2, 1);  // Index.h:373
+  w.keep = keep;
   w.row_bytes = ix->row_bytes;
   w.nchunks = ix->row_bytes / 16;
   int cfg = kNumCfgs - 1;
@@ -804,7 +844,7 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
   const uint32_t per_iter = (uint32_t)(kCfgs[cfg].G * kCfgs[cfg].CU);
   w.q_chunks = (w.nchunks + per_iter - 1) / per_iter * per_iter;
   const bool full = (w.nchunks % per_iter) == 0;
-  w.cap = std::max<uint32_t>((uint32_t)W, ix->M + 1);
+  w.cap = std::max<uint32_t>((uint32_t)W, 4 * ix->M);  // connect prunes row + up to cap - M requesters at a time
   auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
   uint32_t off = 0;
   w.off_q = off;
@@ -812,7 +852,7 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
   uint32_t* offs[] = {&w.off_ckey, &w.off_cid, &w.off_okey, &w.off_oid, &w.off_alive, &w.off_kept, &w.off_sel};
   for (uint32_t* f : offs) {
     *f = off;
-    off = align16(off + w.cap * 4);
+    off = align16(off + (w.cap + 1) * 4);  // + a write-only bin slot
   }
   w.off_stage_ids = off;
   off = align16(off + (WAVE + 1) * 4);
@@ -820,15 +860,22 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
   off = align16(off + (WAVE + 1) * 4);
   const uint32_t lds_bytes = off;
   if (lds_bytes > 160u * 1024u) return fail(FNV_ERR_INVALID, "ef_construction too large for the on-chip wiring state");
-  wire_fn kern = pick_wire_kernel(ix->dtype, ix->metric, cfg, full);
-  HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  int bpc = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, WAVE, lds_bytes));
-  if (bpc < 1) bpc = 1;
-  const uint32_t nslots = (uint32_t)std::min<uint64_t>(count, (uint64_t)bpc * (uint64_t)ix->num_cus);
-  HIP_TRY(hipMemsetAsync(ix->d_dispenser, 0, sizeof(uint32_t), ix->stream));
-  hipLaunchKernelGGL(kern, dim3(nslots), dim3(WAVE), lds_bytes, ix->stream, w);
-  HIP_TRY(hipGetLastError());
+  wire_fn kernels[2] = {pick_wire_kernel(ix->dtype, ix->metric, cfg, full),
+                        pick_connect_kernel(ix->dtype, ix->metric, cfg, full)};
+  HIP_TRY(hipMemsetAsync(ix->d_wirebuf, 0, 16, ix->stream));
+  for (int phase = 0; phase < 2; phase++) {
+    wire_fn kern = kernels[phase];
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    int bpc = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, WAVE, lds_bytes));
+    if (bpc < 1) bpc = 1;
+    // select: one unit of work per new node; connect: per distinct target (at most count * keep, known on the device)
+    const uint64_t units = phase == 0 ? count : count * (uint64_t)keep;
+    const uint32_t nslots = (uint32_t)std::min<uint64_t>(units, (uint64_t)bpc * (uint64_t)ix->num_cus);
+    HIP_TRY(hipMemsetAsync(ix->d_dispenser, 0, sizeof(uint32_t), ix->stream));
+    hipLaunchKernelGGL(kern, dim3(nslots), dim3(WAVE), lds_bytes, ix->stream, w);
+    HIP_TRY(hipGetLastError());
+  }
   std::vector<uint64_t> nd;
   if (evals_out) {
     nd.resize(count);

@@ -3,17 +3,25 @@
 // (include/flatnav/index/Index.h:714-763) and connectNeighbors (:765-834) for a batch of new nodes whose
 // beams (ef_construction nearest wired nodes) the search kernel has just produced.
 //
-// One 64-lane wave wires one new node u:
-//   1. order its beam closest first (equal distances: larger id first, the pop order of the reference's
-//      (-distance, id) priority queue), keep a candidate unless an already kept node is strictly closer to it
-//      than u is, stop at M/2 kept;
-//   2. write u's row (kept nodes, farthest first -- the reference pops a max-heap -- then self-loops);
-//   3. for each kept v, under v's lock: take v's first free (self-loop) slot, else re-prune {u} + row(v)
-//      with the same rule, keep <= M.
+// Two launches per batch, no locks:
+//   wire_select_kernel   one 64-lane wave per new node u: order its beam closest first (equal distances: larger
+//                        id first, the pop order of the reference's (-distance, id) priority queue), keep a
+//                        candidate unless an already kept node is strictly closer to it than u is, stop at M/2
+//                        kept; write u's row (kept nodes farthest first -- the reference pops a max-heap -- then
+//                        self-loops); post one back-link request per kept v on v's request list (an atomicExch
+//                        on head[v] threads the requests of a batch into per-target lists; the first poster
+//                        also appends v to the batch's target list).
+//   wire_connect_kernel  one wave per target v: collect the new nodes that asked for a back-link; if they fit
+//                        v's free (self-loop) slots they take them in order (Index.h:789-797), otherwise
+//                        {row(v)} + {requesters} is re-pruned with the same rule, keep <= M (Index.h:799-829).
+// A wave owns its target's row outright, so hot targets cost one pruning pass over all their requesters
+// instead of a lock hand-off per requester (a first version with per-node spin locks spent 3/4 of its time
+// in hand-offs on hub nodes).  The reference re-prunes once per arriving back-link, in thread arrival order;
+// pruning the union once is a different member of the same family of outcomes.
 // The pruning is evaluated "kept-major": when k is kept, d(k, c) is computed for every remaining candidate c
 // in one gather (batch_dists, the search kernel's distance code) and c is struck out if d(k, c) < d(u, c).
 // That is the same predicate as the reference's candidate-major loop, so given equal distance values the kept
-// set is identical.  Locks are per-node spin locks in HBM; a wave holds one lock at a time, so no cycles.
+// set is identical.
 #pragma once
 #include "distance.hpp"
 #include "heaps.hpp"
@@ -23,7 +31,11 @@ namespace fnv_dev {
 struct WireParams {
   const uint8_t* vectors;  // [capacity][row_bytes]
   uint32_t* links;         // [capacity][M]
-  uint32_t* locks;         // [capacity], 0 = free
+  int32_t* head;           // [capacity] newest request posted for a node this batch, -1 = none (reset by connect)
+  int32_t* req_next;       // [count * keep] request r = i * keep + t (new node first_node + i); next request of
+                           // the same target or -1
+  uint32_t* targets;       // [count * keep] distinct targets of the batch
+  uint32_t* n_targets;
   const float* beam_dist;  // [count][W] ascending
   const int32_t* beam_ids; // [count][W] node ids
   const int32_t* beam_count;
@@ -117,50 +129,55 @@ __device__ __forceinline__ int prune_ordered(const WireParams& p, uint4* qlds, c
   return kept_n;
 }
 
-__device__ __forceinline__ void lock_node(uint32_t* locks, uint32_t node, int lane) {
-  if (lane == 0) {
-    while (true) {
-      unsigned int expected = 0u;
-      if (__hip_atomic_compare_exchange_strong(&locks[node], &expected, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT))
-        break;
-      __builtin_amdgcn_s_sleep(8);
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-__device__ __forceinline__ void unlock_node(uint32_t* locks, uint32_t node, int lane) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  if (lane == 0) __hip_atomic_store(&locks[node], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-
+// d(base, c) for the C candidates in cid[] -> ckey[] (base's vector is staged in qlds first).
 template <typename T, int METRIC, int G, int CU, bool FULL>
-__global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void wire_batch_kernel(const WireParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x;
+__device__ __forceinline__ void keys_from(const WireParams& p, uint4* qlds, uint32_t base, const uint32_t* cid, int C,
+                                          float* ckey, int lane) {
   constexpr int VPW = WAVE / G;
   const int vgrp = lane / G;
-  uint4* qlds = reinterpret_cast<uint4*>(smem + p.off_q);
-  float* ckey = reinterpret_cast<float*>(smem + p.off_ckey);
-  uint32_t* cid = reinterpret_cast<uint32_t*>(smem + p.off_cid);
-  float* okey = reinterpret_cast<float*>(smem + p.off_okey);
-  uint32_t* oid = reinterpret_cast<uint32_t*>(smem + p.off_oid);
-  uint32_t* alive = reinterpret_cast<uint32_t*>(smem + p.off_alive);
-  uint32_t* kept = reinterpret_cast<uint32_t*>(smem + p.off_kept);
-  uint32_t* sel = reinterpret_cast<uint32_t*>(smem + p.off_sel);
-  uint32_t* stage_ids = reinterpret_cast<uint32_t*>(smem + p.off_stage_ids);
-  uint32_t* stage_idx = reinterpret_cast<uint32_t*>(smem + p.off_stage_idx);
-  const int M = (int)p.M;
+  stage_vector(qlds, p.vectors, p.row_bytes, (int)p.nchunks, base, lane);
+  for (int b = 0; b < C; b += VPW * PU) {
+    uint32_t id[PU];
+    float d[PU];
+#pragma unroll
+    for (int pu = 0; pu < PU; pu++) id[pu] = cid[min(b + pu * VPW + vgrp, C - 1)];
+    const int npass = min(PU, (C - b + VPW - 1) / VPW);
+    batch_dists<T, METRIC, G, CU, FULL>(p.vectors, p.row_bytes, (int)p.nchunks, qlds, id, npass, d, lane);
+#pragma unroll
+    for (int pu = 0; pu < PU; pu++) {
+      const int s = b + pu * VPW + vgrp;
+      if (pu < npass && s < C && (lane % G) == 0) ckey[s] = d[pu];
+    }
+  }
+  wave_sync();
+}
+
+#define FNV_WIRE_LDS                                                          \
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];        \
+  const int lane = threadIdx.x;                                               \
+  uint4* qlds = reinterpret_cast<uint4*>(smem + p.off_q);                     \
+  float* ckey = reinterpret_cast<float*>(smem + p.off_ckey);                  \
+  uint32_t* cid = reinterpret_cast<uint32_t*>(smem + p.off_cid);              \
+  float* okey = reinterpret_cast<float*>(smem + p.off_okey);                  \
+  uint32_t* oid = reinterpret_cast<uint32_t*>(smem + p.off_oid);              \
+  uint32_t* alive = reinterpret_cast<uint32_t*>(smem + p.off_alive);          \
+  uint32_t* kept = reinterpret_cast<uint32_t*>(smem + p.off_kept);            \
+  uint32_t* stage_ids = reinterpret_cast<uint32_t*>(smem + p.off_stage_ids);  \
+  uint32_t* stage_idx = reinterpret_cast<uint32_t*>(smem + p.off_stage_idx);  \
+  const int M = (int)p.M;                                                     \
   for (uint32_t c = p.nchunks + lane; c < p.q_chunks; c += WAVE) qlds[c] = make_uint4(0u, 0u, 0u, 0u);
 
+template <typename T, int METRIC, int G, int CU, bool FULL>
+__global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void wire_select_kernel(const WireParams p) {
+  FNV_WIRE_LDS
+  uint32_t* sel = reinterpret_cast<uint32_t*>(smem + p.off_sel);
   while (true) {
     uint32_t i = 0;
     if (lane == 0) i = atomicAdd(p.dispenser, 1u);
     i = (uint32_t)rfl((int)i);
     if (i >= p.count) break;
     const uint32_t u = p.first_node + i;
-
-    // ---- 1. select (Index.h:714-763) ------------------------------------------------------------
+    // ---- select (Index.h:714-763) ---------------------------------------------------------------
     const int C = min(max(rfl(p.beam_count[i]), 0), (int)p.W);
     for (int j = lane; j < C; j += WAVE) {
       ckey[j] = p.beam_dist[(uint64_t)i * p.W + j];
@@ -177,49 +194,77 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void wire_batch_kerne
       kept_n = prune_ordered<T, METRIC, G, CU, FULL>(p, qlds, okey, oid, C, (int)p.keep, alive, kept, stage_ids,
                                                      stage_idx, lane);
     }
-    // ---- 2. u's own row: kept nodes farthest first, then empty (self-loop) slots -------------------
+    // ---- u's own row: kept nodes farthest first, then empty (self-loop) slots ----------------------
     for (int j = lane; j < kept_n; j += WAVE) sel[j] = oid[kept[kept_n - 1 - j]];
     wave_sync();
     for (int j = lane; j < M; j += WAVE) p.links[(uint64_t)u * p.M + j] = j < kept_n ? sel[j] : u;
-
-    // ---- 3. back-links (Index.h:765-834) ---------------------------------------------------------
-    for (int t = 0; t < kept_n; t++) {
-      const uint32_t v = (uint32_t)rfl((int)sel[t]);
-      lock_node(p.locks, v, lane);
-      uint32_t* vrow = p.links + (uint64_t)v * p.M;
-      const uint32_t r = lane < M ? vrow[lane] : v;
-      const unsigned long long freem = __ballot(lane < M && r == v);
-      if (freem) {
-        if (lane == __ffsll((long long)freem) - 1) vrow[lane] = u;
-      } else {
-        // row is full: candidates = {u} + row(v), distances from v, keep <= M by the same rule
-        const int C2 = M + 1;
-        if (lane == 0) cid[0] = u;
-        if (lane < M) cid[1 + lane] = r;
-        stage_vector(qlds, p.vectors, p.row_bytes, (int)p.nchunks, v, lane);
-        for (int b = 0; b < C2; b += VPW * PU) {
-          uint32_t id[PU];
-          float d[PU];
-#pragma unroll
-          for (int pu = 0; pu < PU; pu++) id[pu] = cid[min(b + pu * VPW + vgrp, C2 - 1)];
-          const int npass = min(PU, (C2 - b + VPW - 1) / VPW);
-          batch_dists<T, METRIC, G, CU, FULL>(p.vectors, p.row_bytes, (int)p.nchunks, qlds, id, npass, d, lane);
-#pragma unroll
-          for (int pu = 0; pu < PU; pu++) {
-            const int s = b + pu * VPW + vgrp;
-            if (pu < npass && s < C2 && (lane % G) == 0) ckey[s] = d[pu];
-          }
-        }
-        wave_sync();
-        rank_order(ckey, cid, C2, okey, oid, lane);
-        const int k2 = prune_ordered<T, METRIC, G, CU, FULL>(p, qlds, okey, oid, C2, M, alive, kept, stage_ids,
-                                                             stage_idx, lane);
-        if (lane < M) vrow[lane] = lane < k2 ? oid[kept[k2 - 1 - lane]] : v;
-      }
-      unlock_node(p.locks, v, lane);
+    // ---- post the back-link requests (Index.h:783: "add the reverse edge") -----------------------
+    for (int t = lane; t < kept_n; t += WAVE) {
+      const uint32_t v = sel[t];
+      const int32_t r = (int32_t)(i * p.keep + (uint32_t)t);
+      const int32_t before = atomicExch(&p.head[v], r);
+      p.req_next[r] = before;
+      if (before < 0) p.targets[atomicAdd(p.n_targets, 1u)] = v;
     }
     wave_sync();
   }
 }
+
+template <typename T, int METRIC, int G, int CU, bool FULL>
+__global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void wire_connect_kernel(const WireParams p) {
+  FNV_WIRE_LDS
+  const uint32_t n_targets = *p.n_targets;
+  while (true) {
+    uint32_t j = 0;
+    if (lane == 0) j = atomicAdd(p.dispenser, 1u);
+    j = (uint32_t)rfl((int)j);
+    if (j >= n_targets) break;
+    const uint32_t v = p.targets[j];
+    uint32_t* vrow = p.links + (uint64_t)v * p.M;
+    int32_t r = p.head[v];
+    if (lane == 0) p.head[v] = -1;
+    // row(v): real members first, in slot order
+    const uint32_t mine = lane < M ? vrow[lane] : v;
+    const bool real = lane < M && mine != v;
+    const unsigned long long realm = __ballot(real);
+    int n = __popcll(realm);
+    cid[real ? __popcll(realm & ((1ull << lane) - 1ull)) : (int)p.cap] = mine;  // slot cap = bin
+    const int n_row = n;
+    bool pruned = false;
+    wave_sync();
+    while (true) {
+      // requesters, newest first; as many as the candidate arrays hold
+      while (r >= 0 && n < (int)p.cap) {
+        if (lane == 0) cid[n] = p.first_node + (uint32_t)r / p.keep;
+        n++;
+        r = p.req_next[r];
+      }
+      wave_sync();
+      if (n > M) {  // does not fit: re-prune the union from v's point of view (Index.h:799-829)
+        keys_from<T, METRIC, G, CU, FULL>(p, qlds, v, cid, n, ckey, lane);
+        rank_order(ckey, cid, n, okey, oid, lane);
+        const int k2 = prune_ordered<T, METRIC, G, CU, FULL>(p, qlds, okey, oid, n, M, alive, kept, stage_ids,
+                                                             stage_idx, lane);
+        for (int t = lane; t < k2; t += WAVE) cid[t] = oid[kept[k2 - 1 - t]];  // farthest first, like the pops
+        n = k2;
+        pruned = true;
+        wave_sync();
+      }
+      if (r < 0) break;
+    }
+    if (pruned) {
+      if (lane < M) vrow[lane] = lane < n ? cid[lane] : v;
+    } else {
+      // everything fitted: requesters take the free slots in slot order (Index.h:789-797), members stay put
+      const unsigned long long freem = __ballot(lane < M && !real);
+      if (lane < M && !real) {
+        const int k = __popcll(freem & ((1ull << lane) - 1ull));
+        if (n_row + k < n) vrow[lane] = cid[n_row + k];
+      }
+    }
+    wave_sync();
+  }
+}
+#undef FNV_WIRE_LDS
 
 }  // namespace fnv_dev

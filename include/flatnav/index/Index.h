@@ -535,10 +535,15 @@ class Index {
           {total - row, opt.max_batch, std::max<uint64_t>(256, cur / std::max<uint32_t>(1, opt.growth_divisor))});
       // 1. store the new nodes (vector, label, empty link row) and mirror them to the device; searches
       //    still see only the `cur` nodes that are wired.
-      for (uint64_t i = 0; i < batch; ++i) {
-        node_id_t id;
-        allocateNode(rowPtr(row + i), labels[row + i], id);
-      }
+      auto storeNode = [&](uint32_t i) {  // allocateNode (Index.h:262-272) for slot cur + i
+        const node_id_t id = static_cast<node_id_t>(cur + i);
+        _distance->transformData(nodeData(id), rowPtr(row + i));
+        *nodeLabel(id) = labels[row + i];
+        std::fill_n(nodeLinks(id), _M, id);
+      };
+      for (uint32_t i = 0; i < batch; ++i) storeNode(i);  // a plain copy loop: measured faster than fanning out
+      _cur_num_nodes += batch;
+      markDeviceStale();
       detail::throwOnDeviceError(fnv_index_write_nodes(_device_index, cur, batch, nodeData(static_cast<node_id_t>(cur)),
                                                        _node_size_bytes, _data_size_bytes));
       if (device_wiring) {  // search + prune + wire in HBM; the host rows are refreshed once at the end

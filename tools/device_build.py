@@ -16,6 +16,7 @@ ap.add_argument("--efs", default="50,100,200")
 ap.add_argument("--efc", type=int, default=100)
 ap.add_argument("--max-batch", default="32768")
 ap.add_argument("--skip-host", action="store_true")
+ap.add_argument("--wiring", default="both", choices=["both", "device", "host"])
 args = ap.parse_args()
 NQ, K, M = 10000, 10, 32
 X, Q = ds.sift_like(args.n, NQ) if args.dim == 128 else ds.lowrank_normalized(args.n, NQ, args.dim, 32, 7712)
@@ -42,7 +43,7 @@ if not args.skip_host:
     t0 = time.time(); ix.add(X, args.efc); print("host builder (%d threads): %.1fs" % (threads, time.time() - t0), flush=True)
     report("host", ix); del ix
 for mb in [int(b) for b in args.max_batch.split(",")]:
-  for wiring in (True, False):
+  for wiring in {"both": (True, False), "device": (True,), "host": (False,)}[args.wiring]:
     ix = flatnav.index.create(metric, args.dim, args.n, M, flatnav.data_type.DataType.float32, collect_stats=True)
     ix.set_num_threads(threads)
     t0 = time.time(); ix.add(X, args.efc, device=True, device_max_batch=mb, device_wiring=wiring)
