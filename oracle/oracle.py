@@ -142,7 +142,10 @@ class OracleIndex:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().orc_free(self._h)
+            try:
+                lib().orc_free(self._h)
+            except TypeError:  # interpreter shutdown: module globals are already gone
+                pass
             self._h = None
 
     @property
