@@ -184,7 +184,8 @@ struct fnv_index_s {
   // options
   int64_t visited_factor = 27, visited_slots = 0, visited_floor = 2048, occupancy_target = 13, cand_factor = 2,
           cand_slots = 0, spill_entries = 16384, blocks_per_cu = 0, visited_wide = 0,
-          entry_kernel = 0, output_node_ids = 0;
+          entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0;
+  int64_t overflow_list = -1;  // -1: automatic (a list in HBM only when the bitmap is larger than 512 KB)
   // workspace (grown on demand)
   uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status
   unsigned long long* d_phase = nullptr;  // profiling builds only
@@ -195,6 +196,8 @@ struct fnv_index_s {
   int32_t* d_head = nullptr;     // fnv_index_insert_batch: per-node request list heads (all -1 between launches)
   void* d_wirebuf = nullptr;     // [16 B: n_targets] [count*keep] req_next [count*keep] targets
   size_t wirebuf_bytes = 0;
+  uint32_t* d_ovf = nullptr;  // [nslots][ovf_cap] ids whose bitmap words need clearing (big indexes)
+  size_t ovf_bytes = 0;
   void* d_linkstage = nullptr;  // fnv_index_write_links: [count] ids | [count][M] rows | bad flag
   size_t linkstage_bytes = 0;
   unsigned long long* d_spill = nullptr;
@@ -393,7 +396,7 @@ int fnv_index_free(fnv_index_t ix) {
   if (!ix) return FNV_OK;
   (void)hipSetDevice(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_bitmap, ix->d_linkstage, ix->d_head, ix->d_wirebuf, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase, ix->d_entry};
+  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_bitmap, ix->d_ovf, ix->d_linkstage, ix->d_head, ix->d_wirebuf, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase, ix->d_entry};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (ix->ev0) (void)hipEventDestroy(ix->ev0);
@@ -475,6 +478,8 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   else if (n == "visited_wide") ix->visited_wide = value;
   else if (n == "entry_kernel") ix->entry_kernel = value;
   else if (n == "output_node_ids") ix->output_node_ids = value;
+  else if (n == "overflow_list") ix->overflow_list = value;
+  else if (n == "visited_tag_bits") ix->visited_tag_bits = value;
   else return fail(FNV_ERR_INVALID, "unknown option: " + n);
   return FNV_OK;
 }
@@ -531,6 +536,8 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
   p.cand_slots = std::max<uint32_t>(p.cand_slots, (uint32_t)p.B + 1);  // also hosts the final result list
   p.spill_entries = (uint32_t)ix->spill_entries;
   p.bitmap_words = (uint32_t)(((ix->capacity + 31) / 32 + 3) / 4 * 4);  // whole 16-byte groups: wide clears
+  p.ovf_cap = ix->overflow_list >= 0 ? (uint32_t)ix->overflow_list
+                                     : ((uint64_t)p.bitmap_words * 4 > (512u << 10) ? 16384u : 0u);
 
   const bool full = (p.nchunks % per_iter) == 0;  // rows are whole spans: the lean FULL kernels apply
   kernel_fn kern = pick_kernel(ix->dtype, ix->metric, cfg, full);
@@ -544,15 +551,27 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
     const uint32_t mult = (slots % 3 == 0) ? 3u : 1u;
     uint32_t k = 0;
     for (uint32_t b = slots / 4 / mult; b > 1; b >>= 1) k++;
-    const bool can16 = !ix->visited_wide && nbits <= 30 && k <= nbits && (nbits - k) <= (mult == 3 ? 15u : 14u);
-    if (!can16 && mult == 3) slots = pow2_ceil(slots);  // the 32-bit table needs a power of two
+    const bool can16 = !ix->visited_wide && ix->visited_tag_bits <= 16 && nbits <= 30 && k <= nbits && (nbits - k) <= (mult == 3 ? 15u : 14u);
+    // otherwise 64-bit buckets: three 21-bit tags (slots = 3 * 2^j) or two 32-bit tags (slots = 2^j)
+    const uint32_t w = can16 ? 16u : (slots % 3 == 0 ? 21u : 32u);
+    const uint32_t wbuckets = w == 21 ? slots / 3 : slots / 2;
+    uint32_t wk = 0;
+    for (uint32_t b = wbuckets; b > 1; b >>= 1) wk++;
+    const bool canw = !can16 && !ix->visited_wide && wk <= nbits && (nbits - wk) <= w - 2;
+    if (!can16 && !canw && mult == 3) slots = pow2_ceil(slots);  // the open-addressing table needs a power of two
     p.vis_slots = slots;
-    p.vis_tag16 = can16 ? 1u : 0u;
-    p.vis_mult = mult;
+    p.vis_tag16 = (can16 || canw) ? 1u : 0u;
+    p.vis_w = w;
+    p.vis_mult = can16 ? mult : 1u;
     p.vis_nmask = (uint32_t)((1ull << nbits) - 1ull);
-    p.vis_rshift = can16 ? nbits - k : 0;
-    p.vis_rmask = can16 ? ((1u << p.vis_rshift) - 1u) : 0;
-    p.vis_bytes = can16 ? slots * 2 : slots * 4;
+    p.vis_rshift = can16 ? nbits - k : (canw ? nbits - wk : 0);
+    p.vis_rmask = p.vis_tag16 ? (uint32_t)((1ull << p.vis_rshift) - 1ull) : 0;
+    p.vis_bytes = can16 ? slots * 2 : (canw ? wbuckets * 8 : slots * 4);
+    if (canw) {
+      p.vis_R = w == 21 ? (1ull | (1ull << 21) | (1ull << 42)) : (1ull | (1ull << 32));
+      p.vis_H = p.vis_R << (w - 1);
+      p.vis_Lo = p.vis_R * ((1ull << (w - 1)) - 1ull);
+    }
     p.vis_shift = 32;
     for (uint32_t sft = p.vis_slots; sft > 1; sft >>= 1) p.vis_shift--;
     p.vis_limit = p.vis_slots / 4 * 3;
@@ -605,14 +624,15 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
                               (int)std::min<uint32_t>(lds_bytes, 160u * 1024u));
     const int target = (int)ix->occupancy_target;
     const uint32_t roomy_tag16 = p.vis_tag16;
-    while (pick > 0 && sizes[pick - 1] >= (uint32_t)ix->visited_floor && resident(lds_bytes) < target) {
-      lds_bytes = lay_out(sizes[pick - 1]);
-      if (p.vis_tag16 != roomy_tag16) {  // too few buckets for 16-bit tags at this id width: stop above it
-        lds_bytes = lay_out(sizes[pick]);
-        break;
-      }
-      pick--;
+    for (size_t cand = pick; cand-- > 0 && sizes[cand] >= (uint32_t)ix->visited_floor && resident(lds_bytes) < target;) {
+      const uint32_t smaller = lay_out(sizes[cand]);
+      // not a step down: the tag format lost (too few buckets for this id width), or -- wider tags per slot -- no
+      // fewer bytes than the table already chosen
+      if (p.vis_tag16 != roomy_tag16 || smaller >= lds_bytes) continue;
+      pick = cand;
+      lds_bytes = smaller;
     }
+    lds_bytes = lay_out(sizes[pick]);
   }
   if (lds_bytes > 160u * 1024u)
     return fail(FNV_ERR_INVALID, "ef_search too large for the on-chip beam state (needs " + std::to_string(lds_bytes) +
@@ -635,6 +655,14 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
     HIP_TRY(hipMemset(ix->d_bitmap, 0, need_bitmap));
     ix->bitmap_bytes = need_bitmap;
   }
+  const size_t need_ovf = (size_t)nslots * p.ovf_cap * 4;
+  if (need_ovf > ix->ovf_bytes) {
+    if (ix->d_ovf) HIP_TRY(hipFree(ix->d_ovf));
+    ix->d_ovf = nullptr;
+    ix->ovf_bytes = 0;
+    HIP_TRY(hipMalloc(&ix->d_ovf, need_ovf));
+    ix->ovf_bytes = need_ovf;
+  }
   const size_t need_spill = (size_t)nslots * p.spill_entries * 8;
   if (need_spill > ix->spill_bytes) {
     if (ix->d_spill) HIP_TRY(hipFree(ix->d_spill));
@@ -644,6 +672,7 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
     ix->spill_bytes = need_spill;
   }
   p.ovf_bitmap = ix->d_bitmap;
+  p.ovf_glist = ix->d_ovf;
   p.cand_spill = ix->d_spill;
   p.dispenser = ix->d_dispenser;
   p.status = (int32_t*)(ix->d_dispenser + 1);

@@ -132,6 +132,7 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
   uint32_t* stage_ids = reinterpret_cast<uint32_t*>(smem + p.off_stage_ids);
   uint32_t* bitmap = p.ovf_bitmap + (uint64_t)blockIdx.x * p.bitmap_words;
   uint32_t* ovf_list = reinterpret_cast<uint32_t*>(smem + p.off_ovf);
+  uint32_t* ovf_glist = p.ovf_glist + (uint64_t)blockIdx.x * p.ovf_cap;
   const uint32_t vis_mask = p.vis_slots - 1;
   const int B = p.B;
   const int K = p.K;
@@ -181,7 +182,10 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
     if (lane == 0) {
       if (!p.vis_tag16) visited_insert_lds(vis, vis_mask, p.vis_shift, entry);
     }
-    if (p.vis_tag16) visited_insert_tag16(vis, p, lane == 0, entry, bitmap, ovf_list, ovf);
+    if (p.vis_tag16) {
+      if (p.vis_w == 16) visited_insert_tag16(vis, p, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
+      else visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), p, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
+    }
     ovf = __ballot(ovf) != 0ull;
     int err = ST_OK;
     uint32_t n_dist = 0, n_hops = 0;
@@ -215,7 +219,8 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
         PH_MARK(3);
         bool isnew = false;
         if (p.vis_tag16) {
-          isnew = visited_insert_tag16(vis, p, act, id, bitmap, ovf_list, ovf);
+          if (p.vis_w == 16) isnew = visited_insert_tag16(vis, p, act, id, bitmap, ovf_list, ovf_glist, ovf);
+          else isnew = visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), p, act, id, bitmap, ovf_list, ovf_glist, ovf);
         } else if (act) {
           if (!ovf) {
             isnew = visited_insert_lds(vis, vis_mask, p.vis_shift, id);
@@ -352,8 +357,9 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
     if (ovf) {  // give the spill bitmap back zeroed
       __threadfence();
       const uint32_t listed = ovf_list[0];
-      if (p.vis_tag16 && listed <= OVF_LIST) {  // few ids: clear just their words
-        if ((uint32_t)lane < listed) bitmap[ovf_list[1 + lane] >> 5] = 0u;
+      if (p.vis_tag16 && listed <= OVF_LIST + p.ovf_cap) {  // every id is on record: clear just their words
+        if ((uint32_t)lane < min(listed, OVF_LIST)) bitmap[ovf_list[1 + lane] >> 5] = 0u;
+        for (uint32_t i = OVF_LIST + lane; i < listed; i += WAVE) bitmap[ovf_glist[i - OVF_LIST] >> 5] = 0u;
       } else {
         uint4* b4 = reinterpret_cast<uint4*>(bitmap);
         for (uint32_t i = lane; i < p.bitmap_words / 4; i += WAVE) b4[i] = make_uint4(0u, 0u, 0u, 0u);

@@ -37,6 +37,7 @@ struct SearchParams {
   uint32_t* dispenser;      // next query id
   int32_t* status;          // sticky error flag for the whole launch
   uint32_t* ovf_bitmap;     // [nslots][bitmap_words] visited-set spill (all zero between queries)
+  uint32_t* ovf_glist;      // [nslots][ovf_cap] ids sent to the bitmap beyond the first OVF_LIST (big indexes only)
   unsigned long long* cand_spill;  // [nslots][spill_entries]
   const uint32_t* entry_node;  // [nq] from entry_scan_kernel (null: scan inside the search kernel)
   const float* entry_dist;     // [nq]
@@ -49,12 +50,14 @@ struct SearchParams {
   int K, B;
   uint32_t n_scan, scan_step;
   uint32_t vis_slots, vis_shift, vis_limit;
-  uint32_t vis_tag16;      // 1: 16-bit-tag bucketed table (below), 0: 32-bit open addressing
+  uint32_t vis_tag16;      // 1: bucketed tag table (below; tag width vis_w), 0: 32-bit open addressing
+  uint32_t vis_w;          // 16: four tags per 8-byte bucket; 21 / 32: three / two tags per 64-bit bucket
+  unsigned long long vis_H, vis_Lo, vis_R;  // vis_w > 16: field MSBs, the other field bits, field replication multiplier
   uint32_t vis_bytes;      // LDS bytes of the table
   uint32_t vis_nmask, vis_rshift, vis_rmask;  // tag16: 2^nbits-1, t = nbits-k, 2^t-1
   uint32_t vis_mult;       // tag16: buckets = vis_mult * 2^k with vis_mult in {1, 3}
   uint32_t off_ovf;        // LDS: [0] count, [1..OVF_LIST] ids that went to the HBM bitmap
-  uint32_t cand_slots, spill_entries, bitmap_words;
+  uint32_t cand_slots, spill_entries, bitmap_words, ovf_cap;
   uint32_t off_q, off_nbr, off_cand, off_vis, off_stage_ids;
 };
 

@@ -60,7 +60,8 @@ __device__ __forceinline__ void tag16_slot(const SearchParams& p, uint32_t h, ui
 // short-circuit branches) inside a wave-uniform retry loop that normally runs once, so EXEC is only touched
 // around the CAS itself -- the scalar unit that manipulates EXEC is shared by every wave of the CU.
 __device__ __forceinline__ bool visited_insert_tag16(uint32_t* tab, const SearchParams& p, bool act, uint32_t id,
-                                                     uint32_t* bitmap, uint32_t* ovf_list, bool& used_bitmap) {
+                                                     uint32_t* bitmap, uint32_t* ovf_list, uint32_t* ovf_glist,
+                                                     bool& used_bitmap) {
   uint32_t b1, b2, t1, t2;
   tag16_slot(p, (id * 0x9E3779B1u) & p.vis_nmask, 0u, b1, t1);
   tag16_slot(p, (id * 0x85EBCA6Bu) & p.vis_nmask, 1u, b2, t2);
@@ -98,14 +99,66 @@ __device__ __forceinline__ bool visited_insert_tag16(uint32_t* tab, const Search
         if (!(old & bit)) {
           const uint32_t pos = atomicAdd(&ovf_list[0], 1u);
           // the first OVF_LIST ids are remembered so that a lightly used bitmap is cleared word by word; past
-          // that the whole bitmap is cleared with wide sequential stores (measured faster than scattered
-          // 4-byte clears driven by a longer list kept in HBM)
+          // that the whole bitmap is cleared with wide sequential stores -- measured faster than scattered
+          // 4-byte clears while the bitmap is small (125 KB at 1M nodes); for big indexes (ovf_cap > 0: bitmap
+          // > 512 KB) a longer list in HBM keeps the clean-up proportional to the ids, not to N
           if (pos < OVF_LIST) ovf_list[1 + pos] = id;
+          else if (pos - OVF_LIST < p.ovf_cap) ovf_glist[pos - OVF_LIST] = id;
           isnew = 1u;
         }
       }
     }
     pending = try_cas & (won ^ 1u);  // lost a race for that word: look again
+  }
+  return isnew != 0u;
+}
+
+// The same scheme with 64-bit buckets of three 21-bit or two 32-bit tags, for id ranges whose remainder does not fit
+// 16 bits at an affordable bucket count (N > 2^24 at 4096 slots): tag width w needs nbits - k <= w - 2.
+// zero-field test, exact per field: Z(x) = ~(((x & Lo) + Lo) | x) & H  (H = field MSBs, Lo = the other field bits).
+__device__ __forceinline__ bool visited_insert_tagw(unsigned long long* tab, const SearchParams& p, bool act, uint32_t id,
+                                                    uint32_t* bitmap, uint32_t* ovf_list, uint32_t* ovf_glist,
+                                                    bool& used_bitmap) {
+  const uint32_t h1 = (id * 0x9E3779B1u) & p.vis_nmask, h2 = (id * 0x85EBCA6Bu) & p.vis_nmask;
+  const uint32_t b1 = h1 >> p.vis_rshift, b2 = h2 >> p.vis_rshift;
+  const unsigned long long t1 = ((unsigned long long)(h1 & p.vis_rmask) << 1) + 1ull;
+  const unsigned long long t2 = ((unsigned long long)(h2 & p.vis_rmask) << 1) + 2ull;
+  const unsigned long long H = p.vis_H, Lo = p.vis_Lo;
+  const unsigned long long t1x = t1 * p.vis_R, t2x = t2 * p.vis_R;  // the tag in every field
+  uint32_t pending = act ? 1u : 0u, isnew = 0u;
+  while (__ballot(pending != 0u) != 0ull) {
+    const unsigned long long B1 = tab[b1], B2 = tab[b2];
+#define FNV_ZEROW(x) (~((((x) & Lo) + Lo) | (x)) & H)
+    const unsigned long long hit = FNV_ZEROW(B1 ^ t1x) | FNV_ZEROW(B2 ^ t2x);
+    const unsigned long long z1 = FNV_ZEROW(B1), z2 = FNV_ZEROW(B2);
+#undef FNV_ZEROW
+    const int e1 = __popcll(z1), e2 = __popcll(z2);
+    const uint32_t found = hit != 0ull ? 1u : 0u;
+    const uint32_t full = (e1 | e2) == 0 ? 1u : 0u;
+    const bool first = e1 >= e2;  // insert into the emptier bucket
+    const unsigned long long z = first ? z1 : z2, oldw = first ? B1 : B2, tag = first ? t1 : t2;
+    const int shift = z ? __ffsll((long long)z) - (int)p.vis_w : 0;  // lowest empty field: its MSB is bit shift + w - 1
+    const unsigned long long neww = oldw | (tag << shift);
+    const uint32_t try_cas = pending & (found ^ 1u) & (full ^ 1u);
+    unsigned long long got = ~oldw;
+    if (try_cas) got = atomicCAS(tab + (first ? b1 : b2), oldw, neww);
+    const uint32_t won = try_cas & (got == oldw ? 1u : 0u);
+    isnew |= won;
+    const uint32_t to_bitmap = pending & (found ^ 1u) & full;
+    if (__ballot(to_bitmap != 0u) != 0ull) {
+      if (to_bitmap) {
+        const uint32_t bit = 1u << (id & 31);
+        const uint32_t old = atomicOr(&bitmap[id >> 5], bit);
+        used_bitmap = true;
+        if (!(old & bit)) {
+          const uint32_t pos = atomicAdd(&ovf_list[0], 1u);
+          if (pos < OVF_LIST) ovf_list[1 + pos] = id;
+          else if (pos - OVF_LIST < p.ovf_cap) ovf_glist[pos - OVF_LIST] = id;
+          isnew = 1u;
+        }
+      }
+    }
+    pending = try_cas & (won ^ 1u);
   }
   return isnew != 0u;
 }

@@ -130,6 +130,12 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *                     find both their buckets full go to the per-slot HBM bitmap, results unchanged);
  *                     default 13, 0 = never shrink
  *   "visited_floor"   the table is not shrunk below this many slots (default 2048)
+ *   "visited_tag_bits" 0 = automatic tag width of the bucketed table (16-bit tags while the id range allows it at
+ *                     the chosen size, else three 21-bit or two 32-bit tags per 64-bit bucket); 21 / 32 = never
+ *                     use 16-bit tags (tests)
+ *   "overflow_list"   ids per query slot remembered in HBM so that only the touched words of the overflow
+ *                     bitmap are cleared; default: 16384 when the bitmap (N/8 bytes) exceeds 512 KB, else 0
+ *                     (a small bitmap is cleared whole)
  *   "visited_slots"   force the LDS visited-table size (2^j or 3*2^j; 0 = automatic as above)
  *   "cand_factor"     LDS candidate-heap capacity = cand_factor * beam width + 192 (default 2)
  *   "cand_slots"      force the LDS candidate-heap capacity (0 = from factor)

@@ -151,6 +151,28 @@ def test_spill_paths_stay_exact(oracle_mod, hipmod):
         dev.search(Q, 10, 100)
 
 
+@pytest.mark.parametrize("dt", ["float32", "uint8"])
+def test_wide_tag_visited_tables_stay_exact(oracle_mod, hipmod, dt):
+    # Indexes beyond 2^24 nodes cannot use 16-bit tags at an affordable table size; the kernel then keeps three
+    # 21-bit or two 32-bit tags per 64-bit bucket.  Forced here on a small index: slots = 3*2^j -> 21-bit tags,
+    # slots = 2^j -> 32-bit tags; roomy, undersized (ids overflow to the HBM bitmap), with and without the HBM
+    # overflow list that big indexes use to clear only the bitmap words they touched.
+    X, Q = ds.sift_like(20000, 600)
+    X, Q = X.astype(dt), Q.astype(dt)
+    ix = _build(oracle_mod, "l2", dt, X, 32)
+    dev = _upload(hipmod, ix)
+    dev.set_option("visited_tag_bits", 32)
+    for ef in (50, 200):
+        o = ix.search(Q, 10, ef, stats=True)
+        for slots in (0, 3072, 4096, 384, 256):
+            dev.set_option("visited_slots", slots)
+            for ovf in (0, 64, 16384):
+                dev.set_option("overflow_list", ovf)
+                _assert_exact(o, dev.search(Q, 10, ef, stats=True))
+                g = dev.launch_geometry()
+                assert slots == 0 or g["visited_slots"] == slots
+
+
 def test_labels_and_duplicate_links(oracle_mod, hipmod):
     rng = np.random.default_rng(5)
     X = rng.integers(0, 256, (3000, 64)).astype(np.float32)
