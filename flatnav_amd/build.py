@@ -13,7 +13,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libflatnav_hip.so")
 SOURCES = [os.path.join(CSRC, "beam_search.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, f) for f in ("search_params.h", "heaps.hpp", "distance.hpp", "visited.hpp", "kernels.hpp", "wire.hpp")] + [
+DEPS = SOURCES + [os.path.join(CSRC, f) for f in ("search_params.h", "heaps.hpp", "distance.hpp", "visited.hpp", "kernels.hpp", "wire.hpp", "fast_search.hpp")] + [
     os.path.join(ROOT, "include", "flatnav", "util", "StlExact.h"), os.path.join(ROOT, "include", "flatnav_hip.h")]
 
 

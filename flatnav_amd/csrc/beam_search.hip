@@ -35,6 +35,7 @@
 #include "../../include/flatnav_hip.h"
 #include "kernels.hpp"
 #include "wire.hpp"
+#include "fast_search.hpp"
 
 using namespace fnv_dev;
 
@@ -81,6 +82,18 @@ kernel_fn pick_cfg(int c) {
 }
 
 template <typename T, int METRIC, bool FULL>
+kernel_fn pick_fast_cfg(int c) {
+  switch (c) {
+    case 0: return beam_search_fast_kernel<T, METRIC, 8, 1, FULL>;
+    case 1: return beam_search_fast_kernel<T, METRIC, 8, 2, FULL>;
+    case 2: return beam_search_fast_kernel<T, METRIC, 8, 4, FULL>;
+    case 3: return beam_search_fast_kernel<T, METRIC, 16, 4, FULL>;
+    case 4: return beam_search_fast_kernel<T, METRIC, 32, 4, FULL>;
+    default: return beam_search_fast_kernel<T, METRIC, 64, 4, FULL>;
+  }
+}
+
+template <typename T, int METRIC, bool FULL>
 kernel_fn pick_scan_cfg(int c) {
   switch (c) {
     case 0: return entry_scan_kernel<T, METRIC, 8, 1, FULL>;
@@ -100,9 +113,13 @@ kernel_fn pick_scan_metric(int metric, int cfg, bool full) {
 }
 
 kernel_fn pick_scan_kernel(int dtype, int metric, int cfg, bool full) {
+#ifdef FNV_DEV_FAST_BUILD  // developer builds: one instantiation (float, L2, 128-d rows) compiles in seconds
+  return entry_scan_kernel<float, FNV_METRIC_L2, 8, 4, true>;
+#else
   if (dtype == FNV_DTYPE_FLOAT32) return pick_scan_metric<float>(metric, cfg, full);
   if (dtype == FNV_DTYPE_UINT8) return pick_scan_metric<uint8_t>(metric, cfg, full);
   return pick_scan_metric<int8_t>(metric, cfg, full);
+#endif
 }
 
 template <typename T>
@@ -112,10 +129,31 @@ kernel_fn pick_metric(int metric, int cfg, bool full) {
 }
 
 kernel_fn pick_kernel(int dtype, int metric, int cfg, bool full) {
+#ifdef FNV_DEV_FAST_BUILD  // developer builds: one instantiation (float, L2, 128-d rows) compiles in seconds
+  return beam_search_kernel<float, FNV_METRIC_L2, 8, 4, true>;
+#else
   if (dtype == FNV_DTYPE_FLOAT32) return pick_metric<float>(metric, cfg, full);
   if (dtype == FNV_DTYPE_UINT8) return pick_metric<uint8_t>(metric, cfg, full);
   return pick_metric<int8_t>(metric, cfg, full);
+#endif
 }
+
+template <typename T>
+kernel_fn pick_fast_metric(int metric, int cfg, bool full) {
+  if (metric == FNV_METRIC_L2) return full ? pick_fast_cfg<T, FNV_METRIC_L2, true>(cfg) : pick_fast_cfg<T, FNV_METRIC_L2, false>(cfg);
+  return full ? pick_fast_cfg<T, FNV_METRIC_IP, true>(cfg) : pick_fast_cfg<T, FNV_METRIC_IP, false>(cfg);
+}
+
+kernel_fn pick_fast_kernel(int dtype, int metric, int cfg, bool full) {
+#ifdef FNV_DEV_FAST_BUILD  // developer builds: one instantiation (float, L2, 128-d rows) compiles in seconds
+  return beam_search_fast_kernel<float, FNV_METRIC_L2, 8, 4, true>;
+#else
+  if (dtype == FNV_DTYPE_FLOAT32) return pick_fast_metric<float>(metric, cfg, full);
+  if (dtype == FNV_DTYPE_UINT8) return pick_fast_metric<uint8_t>(metric, cfg, full);
+  return pick_fast_metric<int8_t>(metric, cfg, full);
+#endif
+}
+
 
 typedef void (*wire_fn)(const WireParams);
 
@@ -139,9 +177,13 @@ wire_fn pick_wire_metric(int metric, int cfg, bool full) {
 }
 
 wire_fn pick_wire_kernel(int dtype, int metric, int cfg, bool full) {
+#ifdef FNV_DEV_FAST_BUILD  // developer builds: one instantiation (float, L2, 128-d rows) compiles in seconds
+  return wire_select_kernel<float, FNV_METRIC_L2, 8, 4, true>;
+#else
   if (dtype == FNV_DTYPE_FLOAT32) return pick_wire_metric<float>(metric, cfg, full);
   if (dtype == FNV_DTYPE_UINT8) return pick_wire_metric<uint8_t>(metric, cfg, full);
   return pick_wire_metric<int8_t>(metric, cfg, full);
+#endif
 }
 
 template <typename T, int METRIC, bool FULL>
@@ -164,9 +206,13 @@ wire_fn pick_connect_metric(int metric, int cfg, bool full) {
 }
 
 wire_fn pick_connect_kernel(int dtype, int metric, int cfg, bool full) {
+#ifdef FNV_DEV_FAST_BUILD  // developer builds: one instantiation (float, L2, 128-d rows) compiles in seconds
+  return wire_connect_kernel<float, FNV_METRIC_L2, 8, 4, true>;
+#else
   if (dtype == FNV_DTYPE_FLOAT32) return pick_connect_metric<float>(metric, cfg, full);
   if (dtype == FNV_DTYPE_UINT8) return pick_connect_metric<uint8_t>(metric, cfg, full);
   return pick_connect_metric<int8_t>(metric, cfg, full);
+#endif
 }
 
 }  // namespace
@@ -184,10 +230,12 @@ struct fnv_index_s {
   // options
   int64_t visited_factor = 27, visited_slots = 0, visited_floor = 2048, occupancy_target = 13, cand_factor = 2,
           cand_slots = 0, spill_entries = 16384, blocks_per_cu = 0, visited_wide = 0,
-          entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0;
+          entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0, register_beam = 0;
   int64_t overflow_list = -1;  // -1: automatic (a list in HBM only when the bitmap is larger than 512 KB)
   // workspace (grown on demand)
-  uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status
+  uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status, [2] dispenser of the redo launch, [3] redo count, [4..7] by reason
+  uint32_t* d_redo = nullptr;       // [nq] queries handed from the register-beam kernel to the exact kernel
+  size_t redo_bytes = 0;
   unsigned long long* d_phase = nullptr;  // profiling builds only
   void* d_entry = nullptr;  // [nq] uint32 entry nodes | [nq] float entry distances (K0 output)
   size_t entry_bytes = 0;
@@ -225,8 +273,8 @@ int index_common_init(fnv_index_s* ix) {
   HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&ix->ev0));
   HIP_TRY(hipEventCreate(&ix->ev1));
-  HIP_TRY(hipMalloc(&ix->d_dispenser, 2 * sizeof(uint32_t)));
-  HIP_TRY(hipMemset(ix->d_dispenser, 0, 2 * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&ix->d_dispenser, 8 * sizeof(uint32_t)));
+  HIP_TRY(hipMemset(ix->d_dispenser, 0, 8 * sizeof(uint32_t)));
 #ifdef FNV_PHASE_TIMING
   HIP_TRY(hipMalloc(&ix->d_phase, NPHASE * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(ix->d_phase, 0, NPHASE * sizeof(unsigned long long)));
@@ -396,7 +444,7 @@ int fnv_index_free(fnv_index_t ix) {
   if (!ix) return FNV_OK;
   (void)hipSetDevice(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_bitmap, ix->d_ovf, ix->d_linkstage, ix->d_head, ix->d_wirebuf, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase, ix->d_entry};
+  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_redo, ix->d_bitmap, ix->d_ovf, ix->d_linkstage, ix->d_head, ix->d_wirebuf, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase, ix->d_entry};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (ix->ev0) (void)hipEventDestroy(ix->ev0);
@@ -479,6 +527,7 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   else if (n == "entry_kernel") ix->entry_kernel = value;
   else if (n == "output_node_ids") ix->output_node_ids = value;
   else if (n == "overflow_list") ix->overflow_list = value;
+  else if (n == "register_beam") ix->register_beam = value;
   else if (n == "visited_tag_bits") ix->visited_tag_bits = value;
   else return fail(FNV_ERR_INVALID, "unknown option: " + n);
   return FNV_OK;
@@ -645,8 +694,37 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
   if (ix->blocks_per_cu > 0) bpc = std::min<int>(bpc, (int)ix->blocks_per_cu);
   const uint32_t nslots = (uint32_t)std::min<uint64_t>(nq, (uint64_t)bpc * (uint64_t)ix->num_cus);
 
+  // Optional ("register_beam" = 1): beams of at most 64 entries run in the register-beam kernel first; it hands the
+  // queries in which equal keys met at a decision to the exact (libstdc++-replay) kernel through a redo list
+  // (fast_search.hpp).  Same results; measured 8-14 % SLOWER than the two-heap kernel alone, so it is off by default.
+  const bool fast = ix->register_beam && p.B <= WAVE && p.vis_tag16;
+  SearchParams pf = p;
+  uint32_t lds_fast = 0, nslots_fast = 0;
+  kernel_fn fkern = nullptr;
+  if (fast) {
+    auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+    uint32_t off = 0;
+    pf.off_q = off;
+    off = align16(off + pf.q_chunks * 16);
+    pf.off_vis = off;
+    off = align16(off + pf.vis_bytes);
+    pf.off_stage_ids = off;
+    off = align16(off + (WAVE + 1) * 4);
+    pf.off_ovf = off;
+    off = align16(off + (OVF_LIST + 2) * 4);
+    lds_fast = off;
+    fkern = pick_fast_kernel(ix->dtype, ix->metric, cfg, full);
+    HIP_TRY(hipFuncSetAttribute((const void*)fkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast));
+    int bf = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bf, (const void*)fkern, WAVE, lds_fast));
+    if (bf < 1) bf = 1;
+    if (ix->blocks_per_cu > 0) bf = std::min<int>(bf, (int)ix->blocks_per_cu);
+    nslots_fast = (uint32_t)std::min<uint64_t>(nq, (uint64_t)bf * (uint64_t)ix->num_cus);
+  }
+  const uint32_t nslots_ws = std::max(nslots, nslots_fast);
+
   // workspace
-  const size_t need_bitmap = (size_t)nslots * p.bitmap_words * 4;
+  const size_t need_bitmap = (size_t)nslots_ws * p.bitmap_words * 4;
   if (need_bitmap > ix->bitmap_bytes) {
     if (ix->d_bitmap) HIP_TRY(hipFree(ix->d_bitmap));
     ix->d_bitmap = nullptr;
@@ -655,7 +733,7 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
     HIP_TRY(hipMemset(ix->d_bitmap, 0, need_bitmap));
     ix->bitmap_bytes = need_bitmap;
   }
-  const size_t need_ovf = (size_t)nslots * p.ovf_cap * 4;
+  const size_t need_ovf = (size_t)nslots_ws * p.ovf_cap * 4;
   if (need_ovf > ix->ovf_bytes) {
     if (ix->d_ovf) HIP_TRY(hipFree(ix->d_ovf));
     ix->d_ovf = nullptr;
@@ -678,7 +756,17 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
   p.status = (int32_t*)(ix->d_dispenser + 1);
   p.phase_cycles = ix->d_phase;
 
-  HIP_TRY(hipMemsetAsync(ix->d_dispenser, 0, 2 * sizeof(uint32_t), stream));
+  if (fast) {
+    const size_t need_redo = (size_t)nq * 4;
+    if (need_redo > ix->redo_bytes) {
+      if (ix->d_redo) HIP_TRY(hipFree(ix->d_redo));
+      ix->d_redo = nullptr;
+      ix->redo_bytes = 0;
+      HIP_TRY(hipMalloc(&ix->d_redo, need_redo));
+      ix->redo_bytes = need_redo;
+    }
+  }
+  HIP_TRY(hipMemsetAsync(ix->d_dispenser, 0, 8 * sizeof(uint32_t), stream));
   HIP_TRY(hipEventRecord(ix->ev0, stream));
   if (ix->entry_kernel) {
     // K0: one pass over the shared entry-scan nodes for the whole batch (LDS-staged), same stream
@@ -702,6 +790,19 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
     HIP_TRY(hipGetLastError());
     p.entry_node = p.entry_node_out;
     p.entry_dist = p.entry_dist_out;
+  }
+  if (fast) {
+    pf.ovf_bitmap = p.ovf_bitmap;
+    pf.ovf_glist = p.ovf_glist;
+    pf.dispenser = p.dispenser;
+    pf.status = p.status;
+    pf.entry_node = p.entry_node;
+    pf.entry_dist = p.entry_dist;
+    pf.redo_list = p.redo_list = ix->d_redo;
+    pf.redo_count = p.redo_count = ix->d_dispenser + 3;
+    hipLaunchKernelGGL(fkern, dim3(nslots_fast), dim3(WAVE), lds_fast, stream, pf);
+    HIP_TRY(hipGetLastError());
+    p.dispenser = ix->d_dispenser + 2;  // the exact kernel now walks the redo list (usually empty or short)
   }
   hipLaunchKernelGGL(kern, dim3(nslots), dim3(WAVE), lds_bytes, stream, p);
   HIP_TRY(hipGetLastError());
@@ -964,6 +1065,18 @@ int fnv_debug_phase_cycles(fnv_index_t ix, uint64_t out[16]) {
   return FNV_OK;
 }
 #endif
+
+int fnv_last_replayed_queries(fnv_index_t ix, uint64_t out[5]) {
+  if (!ix || !out) return fail(FNV_ERR_INVALID, "null argument");
+  for (int i = 0; i < 5; i++) out[i] = 0;
+  if (!ix->launched) return FNV_OK;
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(hipStreamSynchronize(ix->last_stream));
+  uint32_t w[5];
+  HIP_TRY(hipMemcpy(w, ix->d_dispenser + 3, sizeof(w), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 5; i++) out[i] = w[i];
+  return FNV_OK;
+}
 
 int fnv_last_launch_geometry(fnv_index_t ix, uint64_t geom[6]) {
   if (!ix || !geom) return fail(FNV_ERR_INVALID, "null argument");

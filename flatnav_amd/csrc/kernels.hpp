@@ -142,7 +142,12 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kern
     int qi = 0;
     if (lane == 0) qi = (int)atomicAdd(p.dispenser, 1u);
     qi = rfl(qi);
-    if ((uint32_t)qi >= p.nq) break;
+    if (p.redo_list) {  // second launch: only the queries the register-beam kernel handed over
+      if ((uint32_t)qi >= *p.redo_count) break;
+      qi = (int)p.redo_list[qi];
+    } else if ((uint32_t)qi >= p.nq) {
+      break;
+    }
     PH_DECL
 
     // ---- stage the query (zero padded) and reset the visited table --------------------------

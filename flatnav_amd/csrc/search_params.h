@@ -34,7 +34,10 @@ struct SearchParams {
   int32_t* out_count;       // [nq] or null
   uint64_t* out_ndist;      // [nq] or null
   uint64_t* out_nhops;      // [nq] or null
-  uint32_t* dispenser;      // next query id
+  uint32_t* dispenser;      // next query id (exact replay of a redo list: next list position)
+  uint32_t* redo_list;      // fast kernel: queries it abandoned (equal keys at a decision); exact kernel: non-null =
+                            // run exactly these
+  uint32_t* redo_count;
   int32_t* status;          // sticky error flag for the whole launch
   uint32_t* ovf_bitmap;     // [nslots][bitmap_words] visited-set spill (all zero between queries)
   uint32_t* ovf_glist;      // [nslots][ovf_cap] ids sent to the bitmap beyond the first OVF_LIST (big indexes only)

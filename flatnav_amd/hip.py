@@ -24,7 +24,7 @@ C_ABI_SYMBOLS = [
     "fnv_index_device_buffers", "fnv_index_info", "fnv_index_free", "fnv_set_option", "fnv_search_batch",
     "fnv_search_batch_device", "fnv_search_status", "fnv_last_kernel_ms", "fnv_last_launch_geometry",
     "fnv_index_set_live_nodes", "fnv_index_write_nodes", "fnv_index_write_links", "fnv_index_insert_batch",
-    "fnv_index_read_links",
+    "fnv_index_read_links", "fnv_last_replayed_queries",
 ]
 
 _lib = None
@@ -68,6 +68,7 @@ def lib() -> C.CDLL:
         C.c_void_p] * 6
     L.fnv_search_status.argtypes = [C.c_void_p]
     L.fnv_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.fnv_last_replayed_queries.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.fnv_last_launch_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     _lib = L
     return L
@@ -213,6 +214,12 @@ class DeviceIndex:
         ms = C.c_float(0)
         check(lib().fnv_last_kernel_ms(self._h, C.byref(ms)))
         return float(ms.value)
+
+    def replayed_queries(self) -> dict:
+        """Queries of the last search that the exact kernel replayed after the register-beam kernel, by reason."""
+        r = (C.c_uint64 * 5)()
+        check(lib().fnv_last_replayed_queries(self._h, r))
+        return dict(zip(["total", "eviction_tie", "selection_tie", "result_tie", "nan_inf"], [int(x) for x in r]))
 
     def launch_geometry(self) -> dict:
         g = (C.c_uint64 * 6)()

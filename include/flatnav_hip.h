@@ -142,6 +142,9 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *   "spill_entries"   per-slot HBM spill capacity of the candidate heap (default 16384)
  *   "blocks_per_cu"   cap resident query slots per CU (0 = occupancy limit)
  *   "output_node_ids" 1 = out_labels receives node ids, not labels (used by the device-assisted builder)
+ *   "register_beam"   1 = beams <= 64 first run in the register-beam kernel (csrc/fast_search.hpp), which hands
+ *                     queries with decision-relevant ties to the exact kernel; same results either way.  Default 0:
+ *                     measured slower than the exact kernel alone on MI355X
  *   "entry_kernel"    1 = entry points of the whole batch come from the LDS-staged entry_scan_kernel (K0);
  *                     0 (default) = every query scans them inside the search kernel.  Same results bit for
  *                     bit; measured equally fast on MI355X (the shared scan rows are L2 hits either way)
@@ -176,6 +179,12 @@ int fnv_search_status(fnv_index_t index);
 /* Duration (ms, HIP events on the launch stream) of the search kernel of the most recent
  * fnv_search_batch[_device] call on this index; synchronises with that launch. */
 int fnv_last_kernel_ms(fnv_index_t index, float* ms);
+
+/* With option "register_beam" beams of at most 64 entries are searched by the register-beam kernel, which hands a
+ * query to the exact (libstdc++-replay) kernel when equal distances meet at a decision.  out[5] = queries of
+ * the most recent search that were replayed: {total, eviction tie, selection tie, result tie, NaN/inf};
+ * synchronises with that launch.  Results do not depend on the split. */
+int fnv_last_replayed_queries(fnv_index_t index, uint64_t out[5]);
 
 /* Launch geometry of the most recent search: geom[6] = {grid_blocks, block_threads, lds_bytes,
  * blocks_per_cu, visited_slots, cand_slots}. */
