@@ -23,6 +23,7 @@ ap.add_argument("--efs", default="100,200,400")
 ap.add_argument("--efc", type=int, default=100)
 ap.add_argument("--chunk", type=int, default=1_000_000)
 ap.add_argument("--oracle-sample", type=int, default=200)
+ap.add_argument("--opt", action="append", default=[], help="name=value[,name=value] option sets to compare at every ef")
 args = ap.parse_args()
 NQ, K, M = 10000, 10, 32
 dev = torch.device("cuda:0")
@@ -76,7 +77,10 @@ torch.cuda.empty_cache()
 d = hip.DeviceIndex(ctypes.c_void_p(ix.device_handle()))
 esz, nscan = 4, -(-args.n // max(1, args.n // 100))
 try:
-    for ef in [int(e) for e in args.efs.split(",")]:
+    for ef, optset in [(int(e), o) for e in args.efs.split(",") for o in (args.opt or [""])]:
+        applied = [kv.split("=") for kv in optset.split(",") if kv]
+        for k, v in applied: d.set_option(k, int(v))
+        if optset: print("options:", optset, flush=True)
         d.search(Qh, K, ef)
         t0 = time.perf_counter(); dd, ll, st = d.search(Qh, K, ef, stats=True); wall = time.perf_counter() - t0
         ms = d.last_kernel_ms()
@@ -84,6 +88,8 @@ try:
         print("ef=%3d: %8.0f QPS kernel (%.2f ms), %8.0f QPS host buffers  recall@10 %.4f  evals/q %.0f  %.2f TB/s algorithmic "
               "(%.2f of 8)  %s" % (ef, NQ / ms * 1e3, ms, NQ / wall, ds.recall_at_k(ll[:NG], gt), st["n_dist"].mean(),
                                   byts / ms / 1e9, byts / ms / 1e9 / 8, d.launch_geometry()), flush=True)
+        defaults = {"cand_factor": 2, "visited_floor": 2048, "visited_factor": 27, "occupancy_target": 13}
+        for k, v in applied: d.set_option(k, defaults.get(k, 0))
     if args.oracle_sample:
         from oracle import oracle as orc
         o = orc.OracleIndex.from_blob(args.metric, "float32", args.dim, args.n, args.n, M, np.asarray(ix._raw_blob()))
