@@ -20,6 +20,10 @@
 // per vector so each lane group reads whole 128-byte lines, PU*CU loads in flight per
 // lane), reduces the distances across lanes with DPP, then replays the reference's
 // sequential admission rule on the results.
+//
+// Also here: incremental construction (fnv_index_write_nodes / write_links / insert_batch: Index::add,
+// include/flatnav/index/Index.h:353-378 with selectNeighbors :714-763 and connectNeighbors :765-834 as the
+// wire_select / wire_connect kernels of wire.hpp) and the optional register-beam kernel (fast_search.hpp).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
