@@ -44,7 +44,14 @@ def replicate_index(dev, device: int, src: int = 0, group=None) -> None:
     from rank `src` with RCCL broadcasts of its three HBM buffers."""
     import torch
 
-    views = [torch.as_tensor(_DevView(ptr, nbytes), device="cuda:%d" % device) for ptr, nbytes in dev.device_buffers()]
+    # broadcast the LIVE rows only: a device-built source may hold room for more nodes than it has, and the
+    # replicas are allocated for the live count
+    live = [dev.n_nodes * dev.row_bytes, dev.n_nodes * dev.M * 4, dev.n_nodes * 4]
+    views = []
+    for (ptr, nbytes), want in zip(dev.device_buffers(), live):
+        if want > nbytes:
+            raise RuntimeError("device buffer smaller than its live rows")
+        views.append(torch.as_tensor(_DevView(ptr, want), device="cuda:%d" % device))
     broadcast_buffers(views, src=src, group=group)
     torch.cuda.synchronize(device)
 
