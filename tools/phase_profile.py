@@ -28,7 +28,7 @@ def main():
     from flatnav_amd import build as hb
 
     if not os.path.exists(PROF_LIB) or args.build_only:
-        hb.build(force=True, defines=["FNV_PHASE_TIMING"], out=PROF_LIB)
+        hb.build(force=True, defines=["FNV_PHASE_TIMING", "FNV_DEV_FAST_BUILD"], out=PROF_LIB)  # float/L2/128-d instantiation only
     if args.build_only:
         return
     os.environ["FLATNAV_HIP_LIB"] = PROF_LIB
@@ -42,7 +42,7 @@ def main():
     index = flatnav.index.create("l2", 128, args.n, 32)
     index.set_num_threads(min(24, os.cpu_count()))
     t0 = time.time()
-    index.add(X, 100)
+    index.add(X, 100, device=True)
     print("build %.1fs" % (time.time() - t0), flush=True)
     dev = hip.DeviceIndex.upload(np.asarray(index._raw_blob()), index._node_size_bytes, index._data_size_bytes, 32,
                                  args.n, "float32", "l2", 128)
