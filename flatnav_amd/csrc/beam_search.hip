@@ -234,7 +234,7 @@ struct fnv_index_s {
   // options
   int64_t visited_factor = 27, visited_slots = 0, visited_floor = 2048, occupancy_target = 13, cand_factor = 2,
           cand_slots = 0, spill_entries = 16384, blocks_per_cu = 0, visited_wide = 0,
-          entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0, register_beam = 0;
+          entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0, register_beam = 2;
   int64_t overflow_list = -1;  // -1: automatic (a list in HBM only when the bitmap is larger than 512 KB)
   // workspace (grown on demand)
   uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status, [2] dispenser of the redo launch, [3] redo count, [4..7] by reason
@@ -698,10 +698,12 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
   if (ix->blocks_per_cu > 0) bpc = std::min<int>(bpc, (int)ix->blocks_per_cu);
   const uint32_t nslots = (uint32_t)std::min<uint64_t>(nq, (uint64_t)bpc * (uint64_t)ix->num_cus);
 
-  // Optional ("register_beam" = 1): beams of at most 64 entries run in the register-beam kernel first; it hands the
-  // queries in which equal keys met at a decision to the exact (libstdc++-replay) kernel through a redo list
-  // (fast_search.hpp).  Same results; measured 8-14 % SLOWER than the two-heap kernel alone, so it is off by default.
-  const bool fast = ix->register_beam && p.B <= WAVE && p.vis_tag16;
+  // "register_beam": beams of at most 64 entries run in the register-beam kernel first; it hands the queries in
+  // which equal keys met at a decision to the exact (libstdc++-replay) kernel through a redo list (fast_search.hpp).
+  // Same results.  Measured 5-8 % faster than the two-heap kernel alone on 1-byte element types (128-byte rows: the
+  // hop is instruction-bound) and 8-14 % slower on float32 rows, hence the default 2 = only for uint8 / int8.
+  const bool want_fast = ix->register_beam == 1 || (ix->register_beam == 2 && dtype_size(ix->dtype) == 1);
+  const bool fast = want_fast && p.B <= WAVE && p.vis_tag16;
   SearchParams pf = p;
   uint32_t lds_fast = 0, nslots_fast = 0;
   kernel_fn fkern = nullptr;

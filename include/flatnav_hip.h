@@ -142,9 +142,9 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *   "spill_entries"   per-slot HBM spill capacity of the candidate heap (default 16384)
  *   "blocks_per_cu"   cap resident query slots per CU (0 = occupancy limit)
  *   "output_node_ids" 1 = out_labels receives node ids, not labels (used by the device-assisted builder)
- *   "register_beam"   1 = beams <= 64 first run in the register-beam kernel (csrc/fast_search.hpp), which hands
- *                     queries with decision-relevant ties to the exact kernel; same results either way.  Default 0:
- *                     measured slower than the exact kernel alone on MI355X
+ *   "register_beam"   beams <= 64 first run in the register-beam kernel (csrc/fast_search.hpp), which hands queries
+ *                     with decision-relevant ties to the exact kernel; same results either way.  0 = never, 1 = always,
+ *                     2 (default) = for uint8 / int8 indexes only (measured +5-8 % there, -8-14 % on float32 rows)
  *   "entry_kernel"    1 = entry points of the whole batch come from the LDS-staged entry_scan_kernel (K0);
  *                     0 (default) = every query scans them inside the search kernel.  Same results bit for
  *                     bit; measured equally fast on MI355X (the shared scan rows are L2 hits either way)

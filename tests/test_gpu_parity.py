@@ -211,6 +211,10 @@ def test_register_beam_kernel_stays_exact(oracle_mod, hipmod, case):
             assert r["total"] > len(Q) // 2
     dev.set_option("visited_slots", 256)  # visited ids overflow into the HBM bitmap in both kernels
     _assert_exact(want, dev.search(Q, 5, 17, stats=True))
+    dev.set_option("visited_slots", 0)
+    dev.set_option("register_beam", 2)  # the default: only 1-byte element types take the register-beam kernel
+    _assert_exact(want, dev.search(Q, 5, 17, stats=True))
+    assert (dev.replayed_queries()["total"] > 0) == (case == "u8_ties")
 
 
 def test_labels_and_duplicate_links(oracle_mod, hipmod):
