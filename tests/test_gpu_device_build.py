@@ -86,6 +86,21 @@ def test_device_build_appends_to_an_existing_graph(flatnav, oracle_mod):
         flatnav.index.create("l2", 100, 10, M).add(X[:5], 64, 0, device=True)
 
 
+def test_device_build_int8_inner_product(flatnav, oracle_mod):
+    rng = np.random.default_rng(3)
+    N, NQ, M, K = 6000, 200, 16, 10
+    X = rng.integers(-20, 21, (N, 48)).astype(np.int8)
+    Q = rng.integers(-20, 21, (NQ, 48)).astype(np.int8)
+    ix = flatnav.index.create("angular", 48, N, M, flatnav.data_type.DataType.int8)
+    ix.set_num_threads(2)
+    ix.add(X, 64, device=True, device_max_batch=1024)
+    _check_graph(ix, N, M)
+    d, l = ix.search(Q, K, 64)
+    o = oracle_mod.OracleIndex.from_blob("angular", "int8", 48, N, N, M, np.asarray(ix._raw_blob()))
+    od, ol = o.search(Q, K, 64)
+    assert (ol == l).all() and (od == d).all()  # integer data: bit-exact, ties included
+
+
 def test_c_abi_incremental_writes_equal_one_upload(oracle_mod):
     N, NQ, M, K = 8000, 400, 16, 10
     X, Q = ds.sift_like(N, NQ)
