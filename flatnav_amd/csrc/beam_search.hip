@@ -250,6 +250,8 @@ struct fnv_index_s {
   size_t wirebuf_bytes = 0;
   uint32_t* d_ovf = nullptr;  // [nslots][ovf_cap] ids whose bitmap words need clearing (big indexes)
   size_t ovf_bytes = 0;
+  void* d_nodestage = nullptr;  // write_nodes: AoS staging chunk + bad flag
+  size_t nodestage_bytes = 0;
   void* d_linkstage = nullptr;  // fnv_index_write_links: [count] ids | [count][M] rows | bad flag
   size_t linkstage_bytes = 0;
   unsigned long long* d_spill = nullptr;
@@ -315,12 +317,18 @@ int write_nodes_impl(fnv_index_s* ix, uint64_t first_node, uint64_t count_nodes,
                      uint64_t node_size, uint64_t data_size, uint64_t id_limit, int* bad_out) {
   HIP_TRY(hipSetDevice(ix->device));
   const uint64_t chunk_nodes = std::max<uint64_t>(1, (256ull << 20) / node_size);
-  uint8_t* d_stage = nullptr;
-  int* d_bad = nullptr;
-  auto cleanup = [&]() {
-    if (d_stage) (void)hipFree(d_stage);
-    if (d_bad) (void)hipFree(d_bad);
-  };
+  // staging area: [chunk of AoS records][bad flag]; kept on the index (a device build writes dozens of batches)
+  const size_t need = std::min(chunk_nodes, count_nodes) * node_size + 16;
+  if (need > ix->nodestage_bytes) {
+    if (ix->d_nodestage) HIP_TRY(hipFree(ix->d_nodestage));
+    ix->d_nodestage = nullptr;
+    ix->nodestage_bytes = 0;
+    HIP_TRY(hipMalloc(&ix->d_nodestage, need));
+    ix->nodestage_bytes = need;
+  }
+  uint8_t* d_stage = (uint8_t*)ix->d_nodestage;
+  int* d_bad = (int*)(d_stage + (need - 16));
+  auto cleanup = [&]() {};
 #define UP_TRY(expr)                                                                                   \
   do {                                                                                                 \
     hipError_t _e = (expr);                                                                            \
@@ -329,8 +337,6 @@ int write_nodes_impl(fnv_index_s* ix, uint64_t first_node, uint64_t count_nodes,
       return fail(FNV_ERR_NO_DEVICE, std::string(#expr) + " failed: " + hipGetErrorString(_e));       \
     }                                                                                                  \
   } while (0)
-  UP_TRY(hipMalloc(&d_stage, std::min(chunk_nodes, count_nodes) * node_size));
-  UP_TRY(hipMalloc(&d_bad, sizeof(int)));
   UP_TRY(hipMemset(d_bad, 0, sizeof(int)));
   const int word_ok = (node_size % 4 == 0 && data_size % 4 == 0) ? 1 : 0;
   for (uint64_t done = 0; done < count_nodes; done += chunk_nodes) {
@@ -408,6 +414,11 @@ int fnv_index_upload(const void* aos_blob, uint64_t node_size, uint64_t data_siz
 
   int bad = 0;
   rc = write_nodes_impl(ix, 0, n_nodes, aos_blob, node_size, data_size, n_nodes, &bad);
+  if (ix->d_nodestage) {  // a one-off upload does not keep its (up to 256 MB) staging chunk
+    (void)hipFree(ix->d_nodestage);
+    ix->d_nodestage = nullptr;
+    ix->nodestage_bytes = 0;
+  }
   if (rc) {
     fnv_index_free(ix);
     return rc;
@@ -448,7 +459,7 @@ int fnv_index_free(fnv_index_t ix) {
   if (!ix) return FNV_OK;
   (void)hipSetDevice(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_redo, ix->d_bitmap, ix->d_ovf, ix->d_linkstage, ix->d_head, ix->d_wirebuf, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase, ix->d_entry};
+  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_redo, ix->d_bitmap, ix->d_ovf, ix->d_nodestage, ix->d_linkstage, ix->d_head, ix->d_wirebuf, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase, ix->d_entry};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (ix->ev0) (void)hipEventDestroy(ix->ev0);
@@ -537,9 +548,22 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   return FNV_OK;
 }
 
+// One batched search launch; node_ids: write node ids instead of labels (the device builder's beams).
+static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq, int K, int ef_search,
+                              int num_initializations, float* d_out_dist, int32_t* d_out_labels, int32_t* d_out_count,
+                              uint64_t* d_out_ndist, uint64_t* d_out_nhops, void* hip_stream, bool node_ids);
+
 int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, int K, int ef_search,
                             int num_initializations, float* d_out_dist, int32_t* d_out_labels,
                             int32_t* d_out_count, uint64_t* d_out_ndist, uint64_t* d_out_nhops, void* hip_stream) {
+  if (!ix) return fail(FNV_ERR_INVALID, "index is null");
+  return search_device_impl(ix, d_queries, nq, K, ef_search, num_initializations, d_out_dist, d_out_labels, d_out_count,
+                            d_out_ndist, d_out_nhops, hip_stream, ix->output_node_ids != 0);
+}
+
+static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq, int K, int ef_search,
+                              int num_initializations, float* d_out_dist, int32_t* d_out_labels, int32_t* d_out_count,
+                              uint64_t* d_out_ndist, uint64_t* d_out_nhops, void* hip_stream, bool node_ids) {
   if (!ix) return fail(FNV_ERR_INVALID, "index is null");
   // Index.h:847-849
   if (num_initializations <= 0) return fail(FNV_ERR_INVALID, "num_initializations must be greater than 0.");
@@ -555,7 +579,7 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
   memset(&p, 0, sizeof(p));
   p.vectors = ix->d_vectors;
   p.links = ix->d_links;
-  p.labels = ix->output_node_ids ? nullptr : ix->d_labels;
+  p.labels = node_ids ? nullptr : ix->d_labels;
   p.queries = (const uint8_t*)d_queries;
   p.out_dist = d_out_dist;
   p.out_labels = d_out_labels;
@@ -943,12 +967,8 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
   // the new nodes' vectors are the queries (Index.h:371: beamSearch(data, entry, ef_construction)); dense rows
   HIP_TRY(hipMemcpy2DAsync(ix->d_q, qrow, ix->d_vectors + first_node * (uint64_t)ix->row_bytes, ix->row_bytes, qrow,
                            count, hipMemcpyDeviceToDevice, ix->stream));
-  const int64_t saved = ix->output_node_ids;
-  ix->output_node_ids = 1;
-  int rc = fnv_search_batch_device(ix, ix->d_q, count, W, W, num_initializations, (float*)(o + o_dist),
-                                   (int32_t*)(o + o_lab), (int32_t*)(o + o_cnt), (uint64_t*)(o + o_nd), nullptr,
-                                   ix->stream);
-  ix->output_node_ids = saved;
+  int rc = search_device_impl(ix, ix->d_q, count, W, W, num_initializations, (float*)(o + o_dist), (int32_t*)(o + o_lab),
+                              (int32_t*)(o + o_cnt), (uint64_t*)(o + o_nd), nullptr, ix->stream, /*node_ids=*/true);
   if (rc) return rc;
 
   std::lock_guard<std::mutex> lock(ix->mu);
