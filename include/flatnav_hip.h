@@ -114,9 +114,10 @@ int fnv_index_write_links(fnv_index_t index, const uint32_t* node_ids, const uin
 
 /* Whole insertions on the device: nodes first_node..first_node+count-1 (records already written with
  * fnv_index_write_nodes, first_node == live count) are searched for with beam width ef_construction
- * against the live graph (Index.h:367-371), then wired by wire_batch_kernel: selectNeighbors to M/2
- * (Index.h:714-763), own row, back-links with re-pruning under per-node locks (connectNeighbors,
- * Index.h:765-834).  On return the batch is live.  evals_out (nullable) receives the distance
+ * against the live graph (Index.h:367-371), then wired by two kernels: wire_select_kernel (selectNeighbors
+ * to M/2, Index.h:714-763; own row; one back-link request per kept neighbour) and wire_connect_kernel (one
+ * wavefront per target node: requesters take free slots, else row + requesters are re-pruned once,
+ * connectNeighbors Index.h:765-834).  On return the batch is live.  evals_out (nullable) receives the distance
  * evaluations of the beam searches (what the reference adds to its counter, Index.h:689-691).
  * max_edges_per_node <= 64.  fnv_index_read_links copies link rows back for the host node store. */
 int fnv_index_insert_batch(fnv_index_t index, uint64_t first_node, uint64_t count, int ef_construction,
