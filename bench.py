@@ -1,24 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- QPS of the batched flat-NSW k-NN search on MI355X (BASELINE.json configs[1]).
+"""bench.py -- QPS of the batched flat-NSW k-NN search on MI355X, one line per BASELINE.json configuration.
 
-One "step" = one pass of the hot path over one batch: `nq` queries (default 10 000) searched
-against an index resident in HBM (default: the SIFT-1M stand-in of SURVEY.md 8d -- 1M x 128
-float32, integer-valued 0..255, L2, M=32, ef_construction=100, ef_search=100, K=10; SIFT itself
-cannot be downloaded here).  Queries and result buffers live in HBM when the timed region starts.
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c3-lowrank|c4|c5] [--index-size n ...]
 
-  python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+One "step" = one pass of the hot path over one batch: `nq` queries (10 000) searched against an index resident in
+HBM; queries and result buffers are in HBM when the timed region starts; every step searches a DIFFERENT batch.
+Configurations (BASELINE.json `configs`, generators of SURVEY.md 8d; no dataset can be downloaded here):
+  c2 (default)  SIFT-1M stand-in S1: 1M x 128 float32, integer-valued, L2           ef by the recall rule (+ ef=100 line)
+  c3            10M x 768 randn, rows normalised, inner product ("angular")        ef=200 as worded (recall is hopeless)
+  c3-lowrank    10M x 768 S3 low-rank unit vectors, inner product                  ef by the recall rule
+  c4            GloVe-1.2M stand-in: 1 183 514 x 100 low-rank unit vectors, IP     ef sweep 50..400, value at the recall rule
+  c5            50M x 128 randn, L2, index replicated per GPU, queries sharded     ef=100
+All with M=32, ef_construction=100, K=10.  The metric's rule: the smallest ef of the sweep with recall@10 >= 0.95,
+recall measured on all 10 000 queries of the first batch against exact brute force.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel
-= beam_search_kernel; achieved = algorithmic bytes per launch / average launch duration from HIP
-events on the launch stream) and, at N=1, `cpu_baseline` (the CPU oracle timed on the host cores).
-Multi-GPU: index replicated with one RCCL broadcast per buffer at load, queries sharded, no
-per-query collective; weak scaling (every rank searches its own nq queries).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel; achieved =
+algorithmic bytes per launch / average launch duration from HIP events on the launch stream), `cpu_baseline` (N=1:
+the CPU oracle timed on the host cores), `secondary` (fixed-ef lines) and `sustained` (>= 1 s of back-to-back steps).
+Multi-GPU: one process per GPU; `--gpus N` without a torch.distributed environment spawns the N ranks itself.
+Index replicated with one RCCL broadcast per buffer at load, queries sharded, no per-query collective; weak scaling.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,48 +37,143 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBPS = 6300.0  # what a streaming float4 copy reaches on this part (same guide)
+
+CONFIGS = {
+    # name: generator, n, dim, metric, dtype, fixed ef (0 = recall rule), sweep, fixed-ef secondary lines
+    "c2": dict(gen="sift_like", n=1_000_000, dim=128, metric="l2", ef=0,
+               sweep=[30, 40, 44, 48, 50, 52, 54, 56, 58, 60, 64, 70, 80, 100, 150, 200, 400], secondary=[100],
+               title="SIFT-1M stand-in (S1 int-lowrank, SURVEY.md 8d)"),
+    "c3": dict(gen="randn_unit", n=10_000_000, dim=768, metric="angular", ef=200, sweep=[], secondary=[],
+               title="C3 as worded: randn rows normalised"),
+    "c3-lowrank": dict(gen="lowrank_unit", n=10_000_000, dim=768, metric="angular", ef=0,
+                       sweep=[100, 200, 300, 400, 600, 800, 1000, 1200, 1600], secondary=[200],
+                       title="C3 recall-qualified variant (S3 low-rank unit vectors, SURVEY.md 8d)"),
+    "c4": dict(gen="glove_like", n=1_183_514, dim=100, metric="angular", ef=0, sweep=[50, 100, 200, 400],
+               secondary=[50, 100, 200, 400], title="GloVe-1.2M stand-in (rank-24 low-rank unit vectors, SURVEY.md 8d)"),
+    "c5": dict(gen="randn", n=50_000_000, dim=128, metric="l2", ef=100, sweep=[], secondary=[],
+               title="C5: randn, index replicated per GPU, queries sharded"),
+}
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def recorded_traffic(n, nq, ef):
-    """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes); None unless this run is the
-    very workload those passes profiled."""
-    path = os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")
-    try:
-        rec = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    for r in rec if isinstance(rec, list) else [rec]:
-        if (r.get("n"), r.get("nq"), r.get("ef")) == (n, nq, ef):
-            return r.get("hbm_bytes_per_launch_corrected")
-    return None
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--index-size", dest="n", type=int, default=0, help="override the configuration's node count")
+    ap.add_argument("--nq", type=int, default=10_000, help="queries per batch per GPU")
+    ap.add_argument("--M", type=int, default=32)
+    ap.add_argument("--efc", type=int, default=100)
+    ap.add_argument("--ef", type=int, default=-1, help="ef_search; 0 = recall rule over --ef-sweep; default: the configuration's")
+    ap.add_argument("--ef-sweep", default="")
+    ap.add_argument("--K", type=int, default=10)
+    ap.add_argument("--builder", default="device", choices=["device", "host"],
+                    help="device: deterministic batched insertion on the GPU (same rule as Index::add); host: the "
+                         "multi-threaded host builder (graph differs from run to run, like the reference's)")
+    ap.add_argument("--build-threads", type=int, default=0)
+    ap.add_argument("--dtype", default="float32", choices=["float32", "uint8"],
+                    help="index element type (uint8: c2 only -- the same integer-valued data stored as bytes)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--sustain-seconds", type=float, default=1.0)
+    ap.add_argument("--opt", action="append", default=[], help="C-ABI option name=value")
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# data
+# ---------------------------------------------------------------------------------------------------------------
+class Data:
+    """Base vectors in chunks (host numpy, the form Index.add takes) and query batches."""
+
+    def __init__(self, cfg, n, nq_total, torch, device):
+        self.cfg, self.n, self.dim = cfg, n, cfg["dim"]
+        gen = cfg["gen"]
+        self.on_device = n > 2_000_000  # big sets are generated by torch on the GPU, chunk by chunk
+        self.torch, self.device = torch, device
+        if not self.on_device:
+            from flatnav_amd import datasets as ds
+
+            if gen == "sift_like":
+                self.X, self.Q = ds.sift_like(n, nq_total)
+            elif gen == "lowrank_unit":
+                self.X, self.Q = ds.lowrank_normalized(n, nq_total, dim=self.dim, rank=32, seed=7712)
+            elif gen == "glove_like":
+                self.X, self.Q = ds.lowrank_normalized(n, nq_total, dim=self.dim, rank=24, seed=100)
+            elif gen == "randn_unit":
+                self.X, self.Q = ds.randn(n, nq_total, self.dim, seed=768, normalize=True)
+            else:
+                self.X, self.Q = ds.randn(n, nq_total, self.dim, seed=50)
+            self.note = "numpy generators of flatnav_amd/datasets.py (SURVEY.md 8d), base first, then queries"
+        else:
+            g = torch.Generator(device=device)
+            seed = {"lowrank_unit": 7712, "glove_like": 100, "randn_unit": 768, "randn": 50, "sift_like": 1296}[gen]
+            g.manual_seed(seed)
+            self.g = g
+            rank = 24 if gen == "glove_like" else 32
+            self.W = None
+            if gen in ("lowrank_unit", "glove_like"):
+                self.W = torch.randn((rank, self.dim), generator=g, device=device) / (rank ** 0.5)
+            if gen == "sift_like":
+                self.W = torch.randn((16, self.dim), generator=g, device=device) / 4
+            self.note = ("same distributions as SURVEY.md 8d, generated chunk-wise by torch on the GPU (seed %d): the "
+                         "random stream differs from numpy's" % seed)
+            self.nq_total = nq_total
+            self.Q = None
+
+    def _gen(self, m):
+        torch, gen, g, dev = self.torch, self.cfg["gen"], self.g, self.device
+        if gen in ("lowrank_unit", "glove_like"):
+            x = torch.randn((m, self.W.shape[0]), generator=g, device=dev) @ self.W
+            x += 0.05 * torch.randn((m, self.dim), generator=g, device=dev)
+        elif gen == "sift_like":
+            x = 64 + 32 * (torch.randn((m, 16), generator=g, device=dev) @ self.W)
+            x += 6 * torch.randn((m, self.dim), generator=g, device=dev)
+            return torch.clip(torch.round(x), 0, 255)
+        else:
+            x = torch.randn((m, self.dim), generator=g, device=dev)
+        if gen != "randn":
+            x /= x.norm(dim=1, keepdim=True)
+        return x
+
+    def chunks(self, rows):
+        """Yields (first, host float32 array) over the base set."""
+        if not self.on_device:
+            for s in range(0, self.n, rows):
+                yield s, self.X[s:s + rows]
+        else:
+            for s in range(0, self.n, rows):
+                yield s, self._gen(min(rows, self.n - s)).cpu().numpy()
+
+    def queries(self):
+        if self.Q is None:
+            self.Q = self._gen(self.nq_total).cpu().numpy()
+        return self.Q
 
 
 def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--index-size", dest="n", type=int, default=1_000_000, help="number of indexed vectors")
-    ap.add_argument("--nq", type=int, default=10_000, help="queries per batch per GPU")
-    ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--M", type=int, default=32)
-    ap.add_argument("--efc", type=int, default=100)
-    ap.add_argument("--ef", type=int, default=0,
-                    help="ef_search; 0 = the metric's rule: smallest ef of --ef-sweep with recall@10 >= 0.95")
-    ap.add_argument("--ef-sweep", default="50,52,54,56,58,60,64,70,80,100,150,200,400")
-    ap.add_argument("--K", type=int, default=10)
-    ap.add_argument("--build-threads", type=int, default=0)
-    ap.add_argument("--dtype", default="float32", choices=["float32", "uint8"],
-                    help="index element type (uint8: the same integer-valued data stored as bytes)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--opt", action="append", default=[], help="C-ABI option name=value")
-    args = ap.parse_args()
+    args = parse_args()
+    # ---- N > 1 without a torch.distributed environment: spawn the ranks (before anything touches the GPU) -------
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        log("[bench] spawning %d ranks: %s" % (args.gpus, " ".join(cmd)))
+        raise SystemExit(subprocess.call(cmd))
 
     import torch
 
@@ -77,9 +181,6 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     # BENCH_SHARE_GPU=1 (testing only): all ranks use cuda:0 and talk over gloo, so the multi-rank control flow
     # can be exercised on a single-GPU box; the real multi-GPU run is one rank per GPU over RCCL.
@@ -100,37 +201,48 @@ def main() -> None:
     from flatnav_amd import datasets as ds
     from flatnav_amd import hip
 
-    N, NQ, DIM, M, K = args.n, args.nq, args.dim, args.M, args.K
-    hw = ds.effective_cpus()  # honours the cgroup CPU quota (16 on the MI355X boxes, 256 CPUs visible)
-
-    # ---- data: every rank generates the same base stream; queries differ per rank (sharding) ----
-    t0 = time.time()
-    X, Q_all = ds.sift_like(N, NQ * world, dim=DIM)
-    Q = np.ascontiguousarray(Q_all[rank * NQ:(rank + 1) * NQ])
+    cfg = dict(CONFIGS[args.config])
+    N = args.n or cfg["n"]
+    NQ, DIM, M, K = args.nq, cfg["dim"], args.M, args.K
+    metric = cfg["metric"]
     DT = args.dtype
+    if DT == "uint8" and cfg["gen"] != "sift_like":
+        raise SystemExit("--dtype uint8 needs the integer-valued c2 data")
     ESIZE = 4 if DT == "float32" else 1
-    if DT == "uint8":
-        X, Q = X.astype(np.uint8), Q.astype(np.uint8)
-    log("[rank %d] data %.1fs" % (rank, time.time() - t0))
+    hw = ds.effective_cpus()  # honours the cgroup CPU quota (16 on the MI355X boxes, 256 CPUs visible)
+    dev_t = torch.device("cuda", local_rank)
 
-    # ---- index: rank 0 builds with the product's host builder, uploads, broadcasts ---------------
-    blob_info = None
+    # ---- data: `nb` distinct query batches per rank (one per step, reused cyclically beyond 32) -------------------
+    nb = max(1, min(args.steps, 32))
+    t0 = time.time()
+    data = Data(cfg, N, NQ * nb * world, torch, dev_t)
+    log("[rank %d] data %.1fs (%s)" % (rank, time.time() - t0, data.note))
+
+    # ---- index: rank 0 builds, the other ranks receive it by RCCL broadcast --------------------------------------
     index = None
+    build_note = ""
     if rank == 0:
         t0 = time.time()
-        index = flatnav.index.create(distance_type="l2", index_data_type=getattr(flatnav.data_type.DataType, DT),
+        index = flatnav.index.create(distance_type=metric, index_data_type=getattr(flatnav.data_type.DataType, DT),
                                      dim=DIM, dataset_size=N, max_edges_per_node=M)
         threads = args.build_threads or max(1, min(hw + hw // 2, os.cpu_count() or 1))
         index.set_num_threads(threads)
-        index.add(data=X, ef_construction=args.efc)
-        log("[rank 0] host build: %d nodes, %d threads, %.1fs" % (N, threads, time.time() - t0))
-        t0 = time.time()
-        blob = np.asarray(index._raw_blob())
-        dev = hip.DeviceIndex.upload(blob, index._node_size_bytes, index._data_size_bytes, M, N, DT, "l2", DIM,
-                                     device=local_rank)
-        log("[rank 0] upload + re-layout to HBM: %.2fs" % (time.time() - t0))
+        index.set_device(local_rank)
+        rows = 1_000_000 if DIM > 256 else 5_000_000
+        for first, xh in data.chunks(rows):
+            if DT == "uint8":
+                xh = xh.astype(np.uint8)
+            index.add(data=xh, ef_construction=args.efc, labels=list(range(first, first + len(xh))),
+                      device=(args.builder == "device"))
+            if data.on_device:
+                log("[rank 0]   %d / %d nodes, %.1fs" % (first + len(xh), N, time.time() - t0))
+        build_s = time.time() - t0
+        build_note = ("device builder (fnv_index_insert_batch: batched insertion on the GPU, deterministic), %.1fs"
+                      if args.builder == "device" else "host builder, %d threads, %%.1fs" % threads) % build_s
+        log("[rank 0] build: %d nodes, %s" % (N, build_note))
+        dev = hip.DeviceIndex(ctypes.c_void_p(index.device_handle()), owned=False)  # the handle belongs to `index`
     else:
-        dev = hip.DeviceIndex.alloc(M, N, DT, "l2", DIM, device=local_rank)
+        dev = hip.DeviceIndex.alloc(M, N, DT, metric, DIM, device=local_rank)
     if world > 1:
         from flatnav_amd import multigpu
 
@@ -141,150 +253,207 @@ def main() -> None:
         k, v = o.split("=")
         dev.set_option(k, int(v))
 
-    # ---- device-resident inputs / outputs ---------------------------------------------------------
-    dq = torch.from_numpy(Q).cuda()
-    d_dist = torch.empty((NQ, K), dtype=torch.float32, device="cuda")
-    d_lab = torch.empty((NQ, K), dtype=torch.int32, device="cuda")
-    d_cnt = torch.empty(NQ, dtype=torch.int32, device="cuda")
-    d_nd = torch.zeros(NQ, dtype=torch.int64, device="cuda")
-    d_nh = torch.zeros(NQ, dtype=torch.int64, device="cuda")
+    # ---- device-resident inputs / outputs -----------------------------------------------------------------------
+    Q_all = data.queries()
+    if DT == "uint8":
+        Q_all = Q_all.astype(np.uint8)
+    Q_rank = np.ascontiguousarray(Q_all[rank * NQ * nb:(rank + 1) * NQ * nb]).reshape(nb, NQ, DIM)
+    dq = torch.from_numpy(Q_rank).to(dev_t)
+    d_dist = torch.empty((NQ, K), dtype=torch.float32, device=dev_t)
+    d_lab = torch.empty((NQ, K), dtype=torch.int32, device=dev_t)
+    d_cnt = torch.empty(NQ, dtype=torch.int32, device=dev_t)
+    d_nd = torch.zeros(NQ, dtype=torch.int64, device=dev_t)
+    d_nh = torch.zeros(NQ, dtype=torch.int64, device=dev_t)
     stream = torch.cuda.current_stream()
 
-    # ---- exact ground truth for recall@10 (brute force on the GPU, first 1000 queries of this rank) ----
-    nrec = min(1000, NQ)
-    xt = torch.from_numpy(X).cuda().float()
-    qt = dq[:nrec].float()
-    xn = (xt * xt).sum(1)
-    gt = torch.empty((nrec, K), dtype=torch.int64, device="cuda")
-    for s0 in range(0, nrec, 250):
-        d2 = xn[None, :] - 2.0 * (qt[s0:s0 + 250] @ xt.T)
-        gt[s0:s0 + 250] = torch.topk(d2, K, dim=1, largest=False).indices
-    gt = gt.cpu().numpy()
-    del xt, xn, qt
-    torch.cuda.empty_cache()
+    # ---- exact ground truth for recall@10: brute force on the GPU against the index's own HBM vector table,
+    #      all NQ queries of this rank's first batch (rank 0 decides ef; every rank needs only ef) ----------------
+    gt = None
+    if rank == 0:
+        t0 = time.time()
+        gt = exact_topk(torch, dev, dq[0], K, N, DIM, DT, metric)
+        log("[rank 0] exact ground truth for %d queries: %.1fs" % (NQ, time.time() - t0))
 
     def recall_at(ef):
-        dev.search_device(dq.data_ptr(), nrec, K, ef, 100, d_dist.data_ptr(), d_lab.data_ptr(), stream=stream.cuda_stream)
+        dev.search_device(dq[0].data_ptr(), NQ, K, ef, 100, d_dist.data_ptr(), d_lab.data_ptr(), stream=stream.cuda_stream)
         torch.cuda.synchronize()
         dev.status()
-        return ds.recall_at_k(d_lab[:nrec].cpu().numpy(), gt)
+        return float((d_lab.long().unsqueeze(2) == gt.unsqueeze(1)).any(dim=2).float().mean().item())
 
-    # ---- ef_search: the metric is QPS at recall@10 >= 0.95 -> smallest swept ef that reaches it (rank 0 decides) ----
-    sweep = {}
-    if args.ef > 0:
-        EF = args.ef
-    else:
-        EF = 0
-        for ef in sorted(int(x) for x in args.ef_sweep.split(",")):
+    # ---- ef_search: fixed by the configuration, or the metric's rule (rank 0 decides) ----------------------------
+    sweep_rec = {}
+    EF = cfg["ef"] if args.ef < 0 else args.ef
+    sweep = [int(x) for x in args.ef_sweep.split(",")] if args.ef_sweep else cfg["sweep"]
+    if EF == 0:
+        for ef in sorted(sweep):
+            ok = False
             if rank == 0:
-                sweep[ef] = round(recall_at(ef), 4)
-                ok = sweep[ef] >= 0.95
-            else:
-                ok = False
+                sweep_rec[ef] = round(recall_at(ef), 4)
+                ok = sweep_rec[ef] >= 0.95
             if dist is not None:
-                flag = torch.tensor([1 if ok else 0], device="cuda")
+                flag = torch.tensor([1 if ok else 0], device=dev_t)
                 dist.broadcast(flag, src=0)
                 ok = bool(flag.item())
             if ok:
                 EF = ef
                 break
         if EF == 0:
-            EF = max(int(x) for x in args.ef_sweep.split(","))
-        log("[rank %d] ef sweep %s -> ef_search=%d" % (rank, sweep, EF))
-
-    def step():
-        dev.search_device(dq.data_ptr(), NQ, K, EF, 100, d_dist.data_ptr(), d_lab.data_ptr(), d_cnt.data_ptr(),
-                          d_nd.data_ptr(), d_nh.data_ptr(), stream=stream.cuda_stream)
+            EF = max(sweep)
+        log("[rank %d] ef sweep %s -> ef_search=%d" % (rank, sweep_rec, EF))
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    dev.status()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for a, b in evs:
-        a.record(stream)
-        step()
-        b.record(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    dev.status()
-    kernel_ms = [a.elapsed_time(b) for a, b in evs]
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def run(ef, steps, warmup, min_seconds=0.0):
+        """Times `steps` launches (batch i mod nb each); returns (elapsed, kernel_ms list, steps done)."""
+        def step(i):
+            dev.search_device(dq[i % nb].data_ptr(), NQ, K, ef, 100, d_dist.data_ptr(), d_lab.data_ptr(),
+                              d_cnt.data_ptr(), d_nd.data_ptr(), d_nh.data_ptr(), stream=stream.cuda_stream)
+        for i in range(warmup):
+            step(i)
+        barrier()
+        dev.status()
+        evs = []
+        barrier()
+        t0 = time.perf_counter()
+        i = 0
+        while True:
+            for _ in range(steps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                step(i)
+                b.record(stream)
+                evs.append((a, b))
+                i += 1
+            if min_seconds <= 0:
+                break
+            torch.cuda.synchronize()
+            if time.perf_counter() - t0 >= min_seconds:
+                break
+        barrier()
+        elapsed = time.perf_counter() - t0
+        dev.status()
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, [a.elapsed_time(b) for a, b in evs], i
 
-    # ---- algorithmic bytes of one launch from the run's own counters --------------
-    nd = d_nd.cpu().numpy().astype(np.int64)
-    nh = d_nh.cpu().numpy().astype(np.int64)
     step_nodes = max(1, N // 100)
     n_scan = (N + step_nodes - 1) // step_nodes
-    bytes_launch = int(((n_scan + nd) * DIM * ESIZE + nh * M * 4 + K * 4).sum())
-    avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
-    achieved = bytes_launch / avg_kernel_s / 1e9
 
+    def launch_bytes(ef, batches):
+        """Algorithmic HBM bytes of one launch, averaged over the given batches, from the kernel's own
+        per-query counters; also mean evaluations / hops per query and the recall of batch 0 when it is among them."""
+        tot, nds, nhs = 0, [], []
+        for b in batches:
+            dev.search_device(dq[b].data_ptr(), NQ, K, ef, 100, d_dist.data_ptr(), d_lab.data_ptr(), d_cnt.data_ptr(),
+                              d_nd.data_ptr(), d_nh.data_ptr(), stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            nd, nh = d_nd.cpu().numpy().astype(np.int64), d_nh.cpu().numpy().astype(np.int64)
+            tot += int(((n_scan + nd) * DIM * ESIZE + nh * M * 4 + K * 4).sum())
+            nds.append(nd.mean())
+            nhs.append(nh.mean())
+        return tot / len(batches), float(np.mean(nds)), float(np.mean(nhs))
+
+    def measure(ef, steps, warmup, min_seconds=0.0):
+        elapsed, kms, done = run(ef, steps, warmup, min_seconds)
+        used = sorted(set(i % nb for i in range(done)))
+        byts, nd_mean, nh_mean = launch_bytes(ef, used[:8])
+        avg_kernel_s = float(np.mean(kms)) / 1e3
+        return dict(elapsed=elapsed, steps=done, qps=NQ * world * done / elapsed, bytes=byts, nd=nd_mean, nh=nh_mean,
+                    kernel_ms=avg_kernel_s * 1e3, achieved=byts / avg_kernel_s / 1e9)
+
+    main_m = measure(EF, args.steps, args.warmup)
     out = None
     if rank == 0:
-        labels = d_lab.cpu().numpy()
-        recall = ds.recall_at_k(labels[:nrec], gt)
+        recall = recall_at(EF)
         geom = dev.launch_geometry()
+        replay = dev.replayed_queries()
         # informational: the host-buffer entry point (pageable H2D of the queries + kernel + D2H of results)
         t0 = time.perf_counter()
-        for _ in range(3):
-            dev.search(Q, K, EF)
+        for i in range(3):
+            dev.search(Q_rank[i % nb], K, EF)
         host_qps = 3 * NQ / (time.perf_counter() - t0)
         log("[rank 0] host-buffer (PCIe-inclusive) path: %.0f queries/s" % host_qps)
-        total_q = NQ * world * args.steps
+    # ---- secondary lines (all ranks take part: the timing barrier is collective) -----------------------------------
+    secondary = []
+    sustained = None
+    if not args.no_secondary:
+        if args.sustain_seconds > 0:
+            sm = measure(EF, max(args.steps, 10), 2, args.sustain_seconds)
+            sustained = {"steps": sm["steps"], "seconds": sm["elapsed"], "value": sm["qps"], "unit": "queries/s",
+                         "ms_per_step": sm["elapsed"] / sm["steps"] * 1e3,
+                         "note": ">= %.1f s of back-to-back steps over %d rotating query batches (the contract line "
+                                 "above times exactly --steps launches)" % (args.sustain_seconds, nb)}
+        for ef2 in cfg["secondary"]:
+            m2 = measure(ef2, max(5, min(args.steps, 20)), 2)
+            rec2 = recall_at(ef2) if rank == 0 else None
+            secondary.append({"ef_search": ef2, "value": m2["qps"], "unit": "queries/s",
+                              "recall_at_10": None if rec2 is None else round(rec2, 4),
+                              "ms_per_step": m2["elapsed"] / m2["steps"] * 1e3, "steps": m2["steps"],
+                              "roofline_frac": m2["achieved"] / HBM_PEAK_GBPS,
+                              "achieved_GBps": m2["achieved"], "mean_dist_evals_per_query": m2["nd"]})
+    if rank == 0:
+        kname = {"two_heaps": "fnv_dev::beam_search_kernel", "sorted_beam_registers": "fnv_dev::beam_search_sorted_kernel",
+                 "sorted_beam_lds": "fnv_dev::beam_search_sorted_kernel"}[geom["kernel"]]
         out = {
             "metric": "qps_at_recall10_ge_0.95",
-            "value": total_q / elapsed,
+            "value": main_m["qps"],
             "unit": "queries/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": main_m["elapsed"] / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if DT == "float32" else "u8",
             "data": "synthetic",
             "config": {
-                "workload": "SIFT-1M stand-in (S1 int-lowrank, SURVEY.md 8d): %d x %d %s L2, M=%d, "
-                            "ef_construction=%d, ef_search=%d, K=%d, %d batched queries per GPU, index in HBM"
-                            % (N, DIM, DT, M, args.efc, EF, K, NQ),
+                "workload": "%s [%s]: %d x %d %s %s, M=%d, ef_construction=%d, ef_search=%d, K=%d, %d batched queries "
+                            "per GPU per step (a different batch every step), index in HBM"
+                            % (args.config, cfg["title"], N, DIM, DT, "L2" if metric == "l2" else "inner product", M,
+                               args.efc, EF, K, NQ),
                 "recall_at_10": round(recall, 4),
+                "recall_queries": NQ,
                 "ef_search": EF,
-                "ef_selection": ("fixed by --ef" if args.ef > 0 else
-                                 "smallest ef of the sweep with recall@10 >= 0.95 (SURVEY.md 8d); recalls: %s" % sweep),
+                "ef_selection": ("fixed (configuration / --ef)" if not sweep_rec else
+                                 "smallest ef of the sweep with recall@10 >= 0.95 on all %d queries of batch 0 "
+                                 "(SURVEY.md 8d); recalls: %s" % (NQ, sweep_rec)),
+                "data_note": data.note,
+                "index_build": build_note,
                 "parallelism": "index replicated x%d, queries sharded" % world,
-                "mean_dist_evals_per_query": float(nd.mean()),
-                "mean_hops_per_query": float(nh.mean()),
+                "mean_dist_evals_per_query": main_m["nd"],
+                "mean_hops_per_query": main_m["nh"],
                 "launch": geom,
+                "queries_replayed_by_exact_kernel": replay["total"],
                 "host_buffer_qps_pcie_inclusive": round(host_qps),
+                "measured_in_this_run": "value, ms_per_step, recall, roofline.achieved/avg_kernel_ms, counters, "
+                                        "secondary, sustained, cpu_baseline; roofline.traffic is null (PMC passes are "
+                                        "separate rocprofv3 runs: see profiles/)",
             },
             "roofline": {
                 "bound": "hbm",
-                # name as rocprofv3 prints it: <element type, metric 0=L2, G lanes per vector, CU loads, FULL rows>
-                "kernel": "fnv_dev::beam_search_kernel<%s, 0, 8, %d, true>" % ("float" if DT == "float32" else "unsigned char",
-                                                                     4 if DT == "float32" else 1),
-                "achieved": achieved,
+                "kernel": kname,
+                "achieved": main_m["achieved"],
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": recorded_traffic(N, NQ, EF),
-                "algorithmic_bytes_per_launch": bytes_launch,
-                "avg_kernel_ms": avg_kernel_s * 1e3,
+                "frac": main_m["achieved"] / HBM_PEAK_GBPS,
+                "frac_of_achievable": main_m["achieved"] / HBM_ACHIEVABLE_GBPS,
+                "traffic": None,
+                "traffic_recorded": recorded_traffic(args.config, N, NQ, EF),
+                "algorithmic_bytes_per_launch": main_m["bytes"],
+                "avg_kernel_ms": main_m["kernel_ms"],
             },
+            "secondary": secondary,
+            "sustained": sustained,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(index, Q, K, EF, hw, labels, DT)
+            out["cpu_baseline"] = cpu_baseline(index, dev, Q_rank[0], K, EF, hw, DT, metric)
+        dev.close()
         del index
     if dist is not None:
         dist.barrier()
@@ -293,32 +462,91 @@ def main() -> None:
         print(json.dumps(out), flush=True)
 
 
-def cpu_baseline(index, Q, K, EF, hw, gpu_labels, dtype="float32"):
-    """The CPU oracle (restated reference search, oracle/) on the same graph and queries, all host
-    threads, bounded to roughly 10-20 s.  Also re-checks GPU == CPU ids on the sample."""
+def exact_topk(torch, dev, q, K, N, DIM, DT, metric, block=250_000):
+    """Exact top-K node labels (== row numbers here) of every query in `q` by brute force against the index's HBM
+    vector table: fp32 GEMM scores per block of rows, exact re-ranking of each block's best 4K candidates."""
+    from flatnav_amd import multigpu
+
+    (vptr, vbytes), _, _ = dev.device_buffers()
+    row_bytes = dev.row_bytes
+    dev_t = q.device
+    table = torch.as_tensor(multigpu._DevView(vptr, N * row_bytes), device=dev_t)
+    qf = q.float()
+    best_s = torch.full((q.shape[0], K), float("inf"), device=dev_t)
+    best_i = torch.zeros((q.shape[0], K), dtype=torch.int64, device=dev_t)
+    for s in range(0, N, block):
+        e = min(N, s + block)
+        rows = table[s * row_bytes:e * row_bytes].view(e - s, row_bytes)
+        if DT == "float32":
+            x = rows.view(torch.float32)[:, :DIM]
+        else:
+            x = rows[:, :DIM].float()
+        for qs in range(0, qf.shape[0], 2500):
+            qq = qf[qs:qs + 2500]
+            if metric == "l2":
+                sc = (x * x).sum(1)[None, :] - 2.0 * (qq @ x.T)
+            else:
+                sc = -(qq @ x.T)
+            cs, ci = torch.topk(sc, min(4 * K, e - s), dim=1, largest=False)
+            # exact scores of the shortlisted rows (the GEMM form of L2 loses digits on large norms)
+            xs = x[ci]  # [q, 4K, dim]
+            ex = ((xs - qq[:, None, :]) ** 2).sum(2) if metric == "l2" else 1.0 - (xs * qq[:, None, :]).sum(2)
+            alls = torch.cat([best_s[qs:qs + 2500], ex], 1)
+            alli = torch.cat([best_i[qs:qs + 2500], ci + s], 1)
+            o = torch.topk(alls, K, dim=1, largest=False).indices
+            best_s[qs:qs + 2500] = alls.gather(1, o)
+            best_i[qs:qs + 2500] = alli.gather(1, o)
+        del x
+    return best_i
+
+
+def recorded_traffic(config, n, nq, ef):
+    """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate runs, corrected as MI355X_MICROARCH.md prescribes) -- a RECORDED number, labelled as such; None unless
+    the committed passes profiled this very workload."""
+    for name in ("r2_pmc_hbm_traffic.json", "pmc_hbm_traffic.json"):
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        for r in rec if isinstance(rec, list) else [rec]:
+            if (r.get("config", "c2"), r.get("n"), r.get("nq"), r.get("ef")) == (config, n, nq, ef):
+                return {"hbm_bytes_per_launch_corrected": r.get("hbm_bytes_per_launch_corrected"),
+                        "source": "profiles/%s (recorded in an earlier rocprofv3 --pmc run, not in this run)" % name}
+    return None
+
+
+def cpu_baseline(index, dev, Q, K, EF, hw, dtype, metric):
+    """The CPU oracle (restated reference search, oracle/) on the same graph and a bounded sample of the same queries,
+    all usable host threads, roughly 10-20 s.  Also re-checks GPU == CPU ids on the sample."""
     from oracle import oracle as orc
 
     orc.build()
     blob = np.asarray(index._raw_blob())
     n = int(index._cur_num_nodes)
-    o = orc.OracleIndex.from_blob("l2", dtype, Q.shape[1], n, n, index.max_edges_per_node, blob)
+    o = orc.OracleIndex.from_blob(metric, dtype, Q.shape[1], n, n, index.max_edges_per_node, blob)
     kind_note = "oracle port, own AVX2 distance"
     if o.use_reference_distance(True):
         kind_note = "oracle port of Index::search driving the reference's own compiled AVX-512 distance kernel (oracle/_ref)"
     threads = hw
-    o.search(Q[:256], K, EF, threads=threads)  # warm
+    t0 = time.perf_counter()
+    o.search(Q[:256], K, EF, threads=threads)  # warm; also sizes the sample
+    per_q = (time.perf_counter() - t0) / 256
+    sample = int(min(len(Q), max(256, 4.0 / max(per_q, 1e-9))))
     reps, t_used, nq_done = 0, 0.0, 0
     ol = None
     while t_used < 8.0 and reps < 50:
         t0 = time.perf_counter()
-        _, ol = o.search(Q, K, EF, threads=threads)
+        _, ol = o.search(Q[:sample], K, EF, threads=threads)
         t_used += time.perf_counter() - t0
-        nq_done += len(Q)
+        nq_done += sample
         reps += 1
+    n1 = int(min(sample, max(64, 2.0 / max(per_q * threads, 1e-9))))
     t0 = time.perf_counter()
-    o.search(Q[:2000], K, EF, threads=1)
-    qps1 = 2000 / (time.perf_counter() - t0)
-    same = float((ol == gpu_labels).all(axis=1).mean())
+    o.search(Q[:n1], K, EF, threads=1)
+    qps1 = n1 / (time.perf_counter() - t0)
+    _, gl = dev.search(Q[:sample], K, EF)
+    same = float((ol == gl).all(axis=1).mean())
     cpu_model = "unknown CPU"
     try:
         for line in open("/proc/cpuinfo"):
@@ -332,9 +560,9 @@ def cpu_baseline(index, Q, K, EF, hw, gpu_labels, dtype="float32"):
         "unit": "queries/s",
         "cores": threads,
         "kind": "port",
-        "sample": "%d x the same %d-query batch on %d host threads (%s); single-thread: %.0f queries/s; "
-                  "GPU ids == CPU ids on %.2f%% of queries; host: %s, %d CPUs visible, %d usable (cgroup quota)"
-                  % (reps, len(Q), threads, kind_note, qps1, same * 100, cpu_model, os.cpu_count() or 0, hw),
+        "sample": "%d x the first %d queries of batch 0 on %d host threads (%s); single-thread: %.0f queries/s; "
+                  "GPU ids == CPU ids on %.2f%% of the sample; host: %s, %d CPUs visible, %d usable (cgroup quota)"
+                  % (reps, sample, threads, kind_note, qps1, same * 100, cpu_model, os.cpu_count() or 0, hw),
     }
 
 

@@ -44,5 +44,30 @@ def build(force: bool = False) -> str:
     return OUT
 
 
+def build_program(src: str, out: str, force: bool = False) -> str:
+    """Compile a C++ program against the header-only host API and the in-tree libflatnav_hip.so (rpath to it)."""
+    from flatnav_amd import build as hip_build
+
+    hip_build.build()
+    deps = [d for d in _deps() if not d.endswith("python_module.cpp")] + [src]
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    cmd = ["g++", "-O2", "-std=c++17", "-march=x86-64-v3", "-ffp-contract=off", "-pthread", "-I" + os.path.join(ROOT, "include"),
+           src, "-o", out, "-L" + HERE, "-lflatnav_hip", "-Wl,-rpath," + HERE]
+    subprocess.check_call(cmd)
+    return out
+
+
+TOOLS = {"flatnav_construct": os.path.join(ROOT, "tools", "flatnav_construct.cpp"),
+         "flatnav_query": os.path.join(ROOT, "tools", "flatnav_query.cpp")}
+
+
+def build_tools(force: bool = False) -> dict:
+    """The construct / query command-line pair (reference tools/construct_npy.cpp, tools/query_npy.cpp)."""
+    return {name: build_program(src, os.path.join(ROOT, "tools", name + ".bin"), force) for name, src in TOOLS.items()}
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    if "--tools" in sys.argv:
+        print(build_tools(force="--force" in sys.argv))

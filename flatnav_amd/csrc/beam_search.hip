@@ -23,8 +23,9 @@
 //
 // Also here: incremental construction (fnv_index_write_nodes / write_links / insert_batch: Index::add,
 // include/flatnav/index/Index.h:353-378 with selectNeighbors :714-763 and connectNeighbors :765-834 as the
-// wire_select / wire_connect kernels of wire.hpp) and the optional register-beam kernel (fast_search.hpp).
+// wire_select / wire_connect kernels of wire.hpp) and the sorted-beam kernels (sorted_beam.hpp).
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -32,14 +33,18 @@
 
 #include <algorithm>
 #include <limits>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/flatnav_hip.h"
+#include "kernel_table.h"
+#ifdef FNV_DEV_FAST_BUILD
 #include "kernels.hpp"
-#include "wire.hpp"
-#include "fast_search.hpp"
+#include "sorted_beam.hpp"
+#endif
+#include "relayout.hpp"
 
 using namespace fnv_dev;
 
@@ -64,162 +69,77 @@ int fail(int code, const std::string& msg) {
 
 size_t dtype_size(int dt) { return dt == FNV_DTYPE_FLOAT32 ? 4 : (dt == FNV_DTYPE_UINT8 || dt == FNV_DTYPE_INT8) ? 1 : 0; }
 
-typedef void (*kernel_fn)(const SearchParams);
-
-struct KernelCfg {
-  int G, CU;
-};
-// chunks covered per inner iteration = G*CU: 8,16,32,64,128,256 (128 B ... 4 KiB of a row)
-const KernelCfg kCfgs[] = {{8, 1}, {8, 2}, {8, 4}, {16, 4}, {32, 4}, {64, 4}};
-constexpr int kNumCfgs = 6;
-
-template <typename T, int METRIC, bool FULL>
-kernel_fn pick_cfg(int c) {
-  switch (c) {
-    case 0: return beam_search_kernel<T, METRIC, 8, 1, FULL>;
-    case 1: return beam_search_kernel<T, METRIC, 8, 2, FULL>;
-    case 2: return beam_search_kernel<T, METRIC, 8, 4, FULL>;
-    case 3: return beam_search_kernel<T, METRIC, 16, 4, FULL>;
-    case 4: return beam_search_kernel<T, METRIC, 32, 4, FULL>;
-    default: return beam_search_kernel<T, METRIC, 64, 4, FULL>;
-  }
-}
-
-template <typename T, int METRIC, bool FULL>
-kernel_fn pick_fast_cfg(int c) {
-  switch (c) {
-    case 0: return beam_search_fast_kernel<T, METRIC, 8, 1, FULL>;
-    case 1: return beam_search_fast_kernel<T, METRIC, 8, 2, FULL>;
-    case 2: return beam_search_fast_kernel<T, METRIC, 8, 4, FULL>;
-    case 3: return beam_search_fast_kernel<T, METRIC, 16, 4, FULL>;
-    case 4: return beam_search_fast_kernel<T, METRIC, 32, 4, FULL>;
-    default: return beam_search_fast_kernel<T, METRIC, 64, 4, FULL>;
-  }
-}
-
-template <typename T, int METRIC, bool FULL>
-kernel_fn pick_scan_cfg(int c) {
-  switch (c) {
-    case 0: return entry_scan_kernel<T, METRIC, 8, 1, FULL>;
-    case 1: return entry_scan_kernel<T, METRIC, 8, 2, FULL>;
-    case 2: return entry_scan_kernel<T, METRIC, 8, 4, FULL>;
-    case 3: return entry_scan_kernel<T, METRIC, 16, 4, FULL>;
-    case 4: return entry_scan_kernel<T, METRIC, 32, 4, FULL>;
-    default: return entry_scan_kernel<T, METRIC, 64, 4, FULL>;
-  }
-}
-
-template <typename T>
-kernel_fn pick_scan_metric(int metric, int cfg, bool full) {
-  if (metric == FNV_METRIC_L2)
-    return full ? pick_scan_cfg<T, FNV_METRIC_L2, true>(cfg) : pick_scan_cfg<T, FNV_METRIC_L2, false>(cfg);
-  return full ? pick_scan_cfg<T, FNV_METRIC_IP, true>(cfg) : pick_scan_cfg<T, FNV_METRIC_IP, false>(cfg);
-}
-
-kernel_fn pick_scan_kernel(int dtype, int metric, int cfg, bool full) {
-#ifdef FNV_DEV_FAST_BUILD  // developer builds: one instantiation (float, L2, 128-d rows) compiles in seconds
-  return entry_scan_kernel<float, FNV_METRIC_L2, 8, 4, true>;
-#else
-  if (dtype == FNV_DTYPE_FLOAT32) return pick_scan_metric<float>(metric, cfg, full);
-  if (dtype == FNV_DTYPE_UINT8) return pick_scan_metric<uint8_t>(metric, cfg, full);
-  return pick_scan_metric<int8_t>(metric, cfg, full);
+// ---- kernel lookup ----------------------------------------------------------------------------------------------
+#ifdef FNV_DEV_FAST_BUILD
+// Developer builds (-DFNV_DEV_FAST_BUILD): ONE translation unit, ONE instantiation per kernel -- element type
+// FNV_DEV_T, L2, G = 8, CU = FNV_DEV_CU, FULL rows -- compiles in seconds (float/4: 128-d f32 rows; unsigned char/1:
+// 128-d u8 rows).  Every table slot points at it.
+#ifndef FNV_DEV_T
+#define FNV_DEV_T float
 #endif
-}
-
-template <typename T>
-kernel_fn pick_metric(int metric, int cfg, bool full) {
-  if (metric == FNV_METRIC_L2) return full ? pick_cfg<T, FNV_METRIC_L2, true>(cfg) : pick_cfg<T, FNV_METRIC_L2, false>(cfg);
-  return full ? pick_cfg<T, FNV_METRIC_IP, true>(cfg) : pick_cfg<T, FNV_METRIC_IP, false>(cfg);
-}
-
-kernel_fn pick_kernel(int dtype, int metric, int cfg, bool full) {
-#ifdef FNV_DEV_FAST_BUILD  // developer builds: one instantiation (float, L2, 128-d rows) compiles in seconds
-  return beam_search_kernel<float, FNV_METRIC_L2, 8, 4, true>;
-#else
-  if (dtype == FNV_DTYPE_FLOAT32) return pick_metric<float>(metric, cfg, full);
-  if (dtype == FNV_DTYPE_UINT8) return pick_metric<uint8_t>(metric, cfg, full);
-  return pick_metric<int8_t>(metric, cfg, full);
+#ifndef FNV_DEV_CU
+#define FNV_DEV_CU 4
 #endif
+const KernelTable& kernel_table(int, int) {
+  static KernelTable t = [] {
+    KernelTable k;
+    for (int c = 0; c < kNumCfgs; c++)
+      for (int f = 0; f < 2; f++) {
+        k.exact[c][f] = beam_search_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
+        k.scan[c][f] = entry_scan_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
+        k.sorted_regs[c][f] = beam_search_sorted_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, false>;
+        k.sorted_lds[c][f] = beam_search_sorted_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, true>;
+        k.select[c][f] = wire_select_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
+        k.connect[c][f] = wire_connect_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
+      }
+    return k;
+  }();
+  return t;
 }
-
-template <typename T>
-kernel_fn pick_fast_metric(int metric, int cfg, bool full) {
-  if (metric == FNV_METRIC_L2) return full ? pick_fast_cfg<T, FNV_METRIC_L2, true>(cfg) : pick_fast_cfg<T, FNV_METRIC_L2, false>(cfg);
-  return full ? pick_fast_cfg<T, FNV_METRIC_IP, true>(cfg) : pick_fast_cfg<T, FNV_METRIC_IP, false>(cfg);
-}
-
-kernel_fn pick_fast_kernel(int dtype, int metric, int cfg, bool full) {
-#ifdef FNV_DEV_FAST_BUILD  // developer builds: one instantiation (float, L2, 128-d rows) compiles in seconds
-  return beam_search_fast_kernel<float, FNV_METRIC_L2, 8, 4, true>;
 #else
-  if (dtype == FNV_DTYPE_FLOAT32) return pick_fast_metric<float>(metric, cfg, full);
-  if (dtype == FNV_DTYPE_UINT8) return pick_fast_metric<uint8_t>(metric, cfg, full);
-  return pick_fast_metric<int8_t>(metric, cfg, full);
+// Product builds: the instantiations live in kernel_inst.hip objects (one per family x element type x metric).
+const KernelTable& kernel_table(int dtype, int metric) {
+  static KernelTable tables[6];
+  static std::once_flag once;
+  std::call_once(once, [] {
+    int i = 0;
+#define FNV_FILL(T, tag, M, mtag)              \
+    fill_exact_##tag##_##mtag(tables[i]);       \
+    fill_sorted_regs_##tag##_##mtag(tables[i]); \
+    fill_sorted_lds_##tag##_##mtag(tables[i]);  \
+    fill_wire_##tag##_##mtag(tables[i]);        \
+    i++;
+    FNV_FOR_EACH_TYPE_METRIC(FNV_FILL)
+#undef FNV_FILL
+  });
+  const int t = dtype == FNV_DTYPE_FLOAT32 ? 0 : dtype == FNV_DTYPE_UINT8 ? 1 : 2;  // order of FNV_FOR_EACH_TYPE_METRIC
+  return tables[2 * t + (metric == FNV_METRIC_IP ? 1 : 0)];
+}
 #endif
+
+kernel_fn pick_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).exact[cfg][full]; }
+kernel_fn pick_scan_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).scan[cfg][full]; }
+kernel_fn pick_sorted_kernel(int dtype, int metric, int cfg, bool full, bool wide) {
+  const KernelTable& t = kernel_table(dtype, metric);
+  return wide ? t.sorted_lds[cfg][full] : t.sorted_regs[cfg][full];
 }
-
-
-typedef void (*wire_fn)(const WireParams);
-
-template <typename T, int METRIC, bool FULL>
-wire_fn pick_wire_cfg(int c) {
-  switch (c) {
-    case 0: return wire_select_kernel<T, METRIC, 8, 1, FULL>;
-    case 1: return wire_select_kernel<T, METRIC, 8, 2, FULL>;
-    case 2: return wire_select_kernel<T, METRIC, 8, 4, FULL>;
-    case 3: return wire_select_kernel<T, METRIC, 16, 4, FULL>;
-    case 4: return wire_select_kernel<T, METRIC, 32, 4, FULL>;
-    default: return wire_select_kernel<T, METRIC, 64, 4, FULL>;
-  }
-}
-
-template <typename T>
-wire_fn pick_wire_metric(int metric, int cfg, bool full) {
-  if (metric == FNV_METRIC_L2)
-    return full ? pick_wire_cfg<T, FNV_METRIC_L2, true>(cfg) : pick_wire_cfg<T, FNV_METRIC_L2, false>(cfg);
-  return full ? pick_wire_cfg<T, FNV_METRIC_IP, true>(cfg) : pick_wire_cfg<T, FNV_METRIC_IP, false>(cfg);
-}
-
-wire_fn pick_wire_kernel(int dtype, int metric, int cfg, bool full) {
-#ifdef FNV_DEV_FAST_BUILD  // developer builds: one instantiation (float, L2, 128-d rows) compiles in seconds
-  return wire_select_kernel<float, FNV_METRIC_L2, 8, 4, true>;
-#else
-  if (dtype == FNV_DTYPE_FLOAT32) return pick_wire_metric<float>(metric, cfg, full);
-  if (dtype == FNV_DTYPE_UINT8) return pick_wire_metric<uint8_t>(metric, cfg, full);
-  return pick_wire_metric<int8_t>(metric, cfg, full);
-#endif
-}
-
-template <typename T, int METRIC, bool FULL>
-wire_fn pick_connect_cfg(int c) {
-  switch (c) {
-    case 0: return wire_connect_kernel<T, METRIC, 8, 1, FULL>;
-    case 1: return wire_connect_kernel<T, METRIC, 8, 2, FULL>;
-    case 2: return wire_connect_kernel<T, METRIC, 8, 4, FULL>;
-    case 3: return wire_connect_kernel<T, METRIC, 16, 4, FULL>;
-    case 4: return wire_connect_kernel<T, METRIC, 32, 4, FULL>;
-    default: return wire_connect_kernel<T, METRIC, 64, 4, FULL>;
-  }
-}
-
-template <typename T>
-wire_fn pick_connect_metric(int metric, int cfg, bool full) {
-  if (metric == FNV_METRIC_L2)
-    return full ? pick_connect_cfg<T, FNV_METRIC_L2, true>(cfg) : pick_connect_cfg<T, FNV_METRIC_L2, false>(cfg);
-  return full ? pick_connect_cfg<T, FNV_METRIC_IP, true>(cfg) : pick_connect_cfg<T, FNV_METRIC_IP, false>(cfg);
-}
-
-wire_fn pick_connect_kernel(int dtype, int metric, int cfg, bool full) {
-#ifdef FNV_DEV_FAST_BUILD  // developer builds: one instantiation (float, L2, 128-d rows) compiles in seconds
-  return wire_connect_kernel<float, FNV_METRIC_L2, 8, 4, true>;
-#else
-  if (dtype == FNV_DTYPE_FLOAT32) return pick_connect_metric<float>(metric, cfg, full);
-  if (dtype == FNV_DTYPE_UINT8) return pick_connect_metric<uint8_t>(metric, cfg, full);
-  return pick_connect_metric<int8_t>(metric, cfg, full);
-#endif
-}
+wire_fn pick_wire_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).select[cfg][full]; }
+wire_fn pick_connect_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).connect[cfg][full]; }
 
 }  // namespace
+
+// What a search launch looks like for one (beam width, K) on one index: cached, because working it out costs
+// several occupancy queries and a single-query search should not pay for them every time.
+struct LaunchPlan {
+  bool valid = false;
+  int B = 0, K = 0, cfg = 0, mode = 0;
+  bool full = false;
+  uint64_t capacity = 0, options_version = 0;
+  kernel_fn kern = nullptr, skern = nullptr;  // exact two-heap kernel; sorted-beam kernel (mode != 0)
+  SearchParams heaps, sorted;                 // geometry + LDS layout for each (per-call fields unset)
+  uint32_t lds = 0, slds = 0;
+  int bpc = 0, sbpc = 0;
+};
 
 struct fnv_index_s {
   int device = 0;
@@ -234,19 +154,27 @@ struct fnv_index_s {
   // options
   int64_t visited_factor = 27, visited_slots = 0, visited_floor = 2048, occupancy_target = 13, cand_factor = 2,
           cand_slots = 0, spill_entries = 16384, blocks_per_cu = 0, visited_wide = 0,
-          entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0, register_beam = 2;
+          entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0, register_beam = 2, sorted_beam = 2,
+          sorted_beam_min = 1, sorted_cand_lds = 2;
+  uint64_t options_version = 0;
+  LaunchPlan plan;
+  // adaptive kernel choice ("sorted_beam" = 2): per beam width, the best time per query seen for each kernel
+  struct Tuner {
+    float best[2] = {-1.f, -1.f};  // ms per query: [0] two-heap kernel, [1] sorted-beam kernel
+    int samples[2] = {0, 0};
+  };
+  std::map<int, Tuner> tuner;
+  int sample_B = 0, sample_kernel = -1;  // the launch between ev0 / ev1 is a sample for this entry (-1: it is not)
+  uint64_t sample_nq = 0;
   int64_t overflow_list = -1;  // -1: automatic (a list in HBM only when the bitmap is larger than 512 KB)
   // workspace (grown on demand)
-  uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status, [2] dispenser of the redo launch, [3] redo count, [4..7] by reason
-  uint32_t* d_redo = nullptr;       // [nq] queries handed from the register-beam kernel to the exact kernel
-  size_t redo_bytes = 0;
+  uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status, [3] queries a sorted-beam launch searched exactly, [4..7] by reason
   unsigned long long* d_phase = nullptr;  // profiling builds only
   void* d_entry = nullptr;  // [nq] uint32 entry nodes | [nq] float entry distances (K0 output)
   size_t entry_bytes = 0;
   uint32_t* d_bitmap = nullptr;
   size_t bitmap_bytes = 0;
-  int32_t* d_head = nullptr;     // fnv_index_insert_batch: per-node request list heads (all -1 between launches)
-  void* d_wirebuf = nullptr;     // [16 B: n_targets] [count*keep] req_next [count*keep] targets
+  void* d_wirebuf = nullptr;  // fnv_index_insert_batch: [count*keep] x {req_target, req_index, sorted_target, sorted_req} | sort scratch
   size_t wirebuf_bytes = 0;
   uint32_t* d_ovf = nullptr;  // [nslots][ovf_cap] ids whose bitmap words need clearing (big indexes)
   size_t ovf_bytes = 0;
@@ -265,7 +193,7 @@ struct fnv_index_s {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t last_stream = nullptr;
   bool launched = false;
-  uint64_t geom[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t geom[7] = {0, 0, 0, 0, 0, 0, 0};
   std::mutex mu;       // launch configuration + workspace growth
   std::mutex host_mu;  // the host-buffer entry point owns d_q / d_out / stream for the whole call
 };
@@ -459,7 +387,7 @@ int fnv_index_free(fnv_index_t ix) {
   if (!ix) return FNV_OK;
   (void)hipSetDevice(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_redo, ix->d_bitmap, ix->d_ovf, ix->d_nodestage, ix->d_linkstage, ix->d_head, ix->d_wirebuf, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase, ix->d_entry};
+  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_bitmap, ix->d_ovf, ix->d_nodestage, ix->d_linkstage, ix->d_wirebuf, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase, ix->d_entry};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (ix->ev0) (void)hipEventDestroy(ix->ev0);
@@ -543,8 +471,14 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   else if (n == "output_node_ids") ix->output_node_ids = value;
   else if (n == "overflow_list") ix->overflow_list = value;
   else if (n == "register_beam") ix->register_beam = value;
+  else if (n == "sorted_beam") ix->sorted_beam = value;
+  else if (n == "sorted_beam_min") ix->sorted_beam_min = value;
+  else if (n == "sorted_cand_lds") ix->sorted_cand_lds = value;
   else if (n == "visited_tag_bits") ix->visited_tag_bits = value;
   else return fail(FNV_ERR_INVALID, "unknown option: " + n);
+  ix->options_version++;
+  ix->tuner.clear();
+  ix->sample_kernel = -1;
   return FNV_OK;
 }
 
@@ -561,6 +495,126 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
                             d_out_ndist, d_out_nhops, hip_stream, ix->output_node_ids != 0);
 }
 
+// ---- launch configuration ---------------------------------------------------------------------------------
+// How a query slot's LDS is laid out depends on the kernel: the two-heap kernel keeps {query, neighbours heap,
+// candidates heap, visited table, staging}; the sorted-beam kernels keep {query, [beam array], visited table, staging}.
+enum { MODE_HEAPS = 0, MODE_SORTED_REGS = 1, MODE_SORTED_LDS = 2 };
+
+// Visited-table geometry for a table of `slots` (2^j or 3*2^j) and the LDS layout that follows from it; returns the
+// bytes of LDS one query slot needs.  16-bit tags whenever the per-bucket id range fits 14 bits: buckets =
+// mult*2^k, t = nbits - k, need t <= 14 (mult 1) or t <= 15 (mult 3).
+static uint32_t lay_out(const fnv_index_s* ix, SearchParams& p, uint32_t slots, int mode) {
+  uint32_t nbits = 1;
+  while (nbits < 32 && (1ull << nbits) < ix->capacity) nbits++;
+  const uint32_t mult = (slots % 3 == 0) ? 3u : 1u;
+  uint32_t k = 0;
+  for (uint32_t b = slots / 4 / mult; b > 1; b >>= 1) k++;
+  const bool can16 = !ix->visited_wide && ix->visited_tag_bits <= 16 && nbits <= 30 && k <= nbits && (nbits - k) <= (mult == 3 ? 15u : 14u);
+  // otherwise 64-bit buckets: three 21-bit tags (slots = 3 * 2^j) or two 32-bit tags (slots = 2^j)
+  const uint32_t w = can16 ? 16u : (slots % 3 == 0 ? 21u : 32u);
+  const uint32_t wbuckets = w == 21 ? slots / 3 : slots / 2;
+  uint32_t wk = 0;
+  for (uint32_t b = wbuckets; b > 1; b >>= 1) wk++;
+  const bool canw = !can16 && !ix->visited_wide && wk <= nbits && (nbits - wk) <= w - 2;
+  if (!can16 && !canw && mult == 3) slots = pow2_ceil(slots);  // the open-addressing table needs a power of two
+  p.vis_slots = slots;
+  p.vis_tag16 = (can16 || canw) ? 1u : 0u;
+  p.vis_w = w;
+  p.vis_mult = can16 ? mult : 1u;
+  p.vis_nmask = (uint32_t)((1ull << nbits) - 1ull);
+  p.vis_rshift = can16 ? nbits - k : (canw ? nbits - wk : 0);
+  p.vis_rmask = p.vis_tag16 ? (uint32_t)((1ull << p.vis_rshift) - 1ull) : 0;
+  p.vis_bytes = can16 ? slots * 2 : (canw ? wbuckets * 8 : slots * 4);
+  p.vis_shift = 32;
+  for (uint32_t sft = p.vis_slots; sft > 1; sft >>= 1) p.vis_shift--;
+  p.vis_limit = p.vis_slots / 4 * 3;
+
+  auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+  uint32_t off = 0;
+  p.off_q = off;
+  off = align16(off + p.q_chunks * 16);
+  // neighbours heap (exact search) / sorted beam: arrays start at 16n + 8 so that child pairs are 16-byte aligned
+  p.off_nbr = off + 8;
+  off = align16(off + 8 + ((uint32_t)p.B + 2) * 8);
+  p.off_cand = off + 8;  // candidates heap of the exact search: cand_slots entries in LDS (0: all of it in HBM)
+  if (p.cand_slots) off = align16(off + 8 + (p.cand_slots + 1) * 8);
+  p.off_vis = off;
+  off = align16(off + p.vis_bytes);
+  p.off_stage_ids = off;
+  off = align16(off + (WAVE + 1) * 4);  // + one write-only slot for lanes with nothing to stage
+  p.off_ovf = off;
+  off = align16(off + (OVF_LIST + 2) * 4);
+  return off;
+}
+
+// Chooses the visited-table size for `kern` in `mode`, fills p's geometry/layout fields; outputs the LDS bytes per
+// slot and the slots one CU keeps resident.
+// Table sizes, ascending: 256, 384, 512, 768, ...  The roomy size (visited_factor * B + 600, <= 60 % load on the
+// reference workloads) keeps every id in LDS; but LDS is also what limits how many queries a CU keeps in flight, and
+// a lone wave issues slowly -- below ~13 resident queries per CU the loss of latency hiding costs more than sending
+// part of the ids to the HBM bitmap (measured: profiles/r1_visited_sizing.md).  So: the largest size <= roomy that
+// still leaves `occupancy_target` queries per CU, but never below visited_floor slots.
+static int configure_launch(fnv_index_s* ix, SearchParams& p, kernel_fn kern, int mode, uint32_t* lds_out, int* bpc_out) {
+  auto resident = [&](uint32_t lds) -> int {  // query slots one CU can hold with this much LDS each
+    if (lds > 160u * 1024u) return 0;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kern, WAVE, lds) != hipSuccess) n = 0;
+    return n;
+  };
+  uint32_t lds_bytes;
+  if (ix->visited_slots) {
+    lds_bytes = lay_out(ix, p, (uint32_t)ix->visited_slots, mode);
+  } else {
+    const uint64_t want = std::max<uint64_t>((uint64_t)ix->visited_factor * (uint64_t)p.B + 600, 256);
+    std::vector<uint32_t> sizes;
+    for (uint32_t base = 256; base <= (1u << 15); base <<= 1) {
+      sizes.push_back(base);
+      if (base >= want) break;
+      if (base < (1u << 15)) {
+        sizes.push_back(base / 2 * 3);
+        if ((uint64_t)base / 2 * 3 >= want) break;
+      }
+    }
+    size_t pick = sizes.size() - 1;  // roomy
+    lds_bytes = lay_out(ix, p, sizes[pick], mode);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)std::min<uint32_t>(lds_bytes, 160u * 1024u));
+    const int target = (int)ix->occupancy_target;
+    const uint32_t roomy_tag16 = p.vis_tag16;
+    for (size_t cand = pick; cand-- > 0 && sizes[cand] >= (uint32_t)ix->visited_floor && resident(lds_bytes) < target;) {
+      const uint32_t smaller = lay_out(ix, p, sizes[cand], mode);
+      // not a step down: the tag format lost (too few buckets for this id width), or -- wider tags per slot -- no
+      // fewer bytes than the table already chosen
+      if (p.vis_tag16 != roomy_tag16 || smaller >= lds_bytes) continue;
+      pick = cand;
+      lds_bytes = smaller;
+    }
+    lds_bytes = lay_out(ix, p, sizes[pick], mode);
+  }
+  if (lds_bytes > 160u * 1024u)
+    return fail(FNV_ERR_INVALID, "ef_search too large for the on-chip beam state (needs " + std::to_string(lds_bytes) +
+                                     " bytes of LDS, 163840 available); lower ef_search or the *_slots options");
+  HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  int bpc = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, WAVE, lds_bytes));
+  if (bpc < 1) bpc = 1;
+  if (ix->blocks_per_cu > 0) bpc = std::min<int>(bpc, (int)ix->blocks_per_cu);
+  *lds_out = lds_bytes;
+  *bpc_out = bpc;
+  return FNV_OK;
+}
+
+static int grow(void** buf, size_t* have, size_t need, bool zero = false) {
+  if (need <= *have) return FNV_OK;
+  if (*buf) HIP_TRY(hipFree(*buf));
+  *buf = nullptr;
+  *have = 0;
+  HIP_TRY(hipMalloc(buf, need));
+  if (zero) HIP_TRY(hipMemset(*buf, 0, need));
+  *have = need;
+  return FNV_OK;
+}
+
 static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq, int K, int ef_search,
                               int num_initializations, float* d_out_dist, int32_t* d_out_labels, int32_t* d_out_count,
                               uint64_t* d_out_ndist, uint64_t* d_out_nhops, void* hip_stream, bool node_ids) {
@@ -575,10 +629,116 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t stream = (hipStream_t)hip_stream;
 
-  SearchParams p;
-  memset(&p, 0, sizeof(p));
-  p.vectors = ix->d_vectors;
-  p.links = ix->d_links;
+  // ---- launch plan: depends on (beam width, K, live geometry, options) only -> cached between calls ------------
+  const int B = std::max(ef_search, K);  // Index.h:392
+  LaunchPlan& plan = ix->plan;
+  if (!(plan.valid && plan.B == B && plan.K == K && plan.capacity == ix->capacity &&
+        plan.options_version == ix->options_version)) {
+    plan = LaunchPlan();
+    SearchParams p;
+    memset(&p, 0, sizeof(p));
+    p.vectors = ix->d_vectors;
+    p.links = ix->d_links;
+    p.M = ix->M;
+    p.dim = ix->dim;
+    p.row_bytes = ix->row_bytes;
+    p.nchunks = ix->row_bytes / 16;
+    p.K = K;
+    p.B = B;
+    int cfg = kNumCfgs - 1;
+    for (int c = 0; c < kNumCfgs; c++)
+      if ((uint32_t)(kCfgs[c].G * kCfgs[c].CU) >= p.nchunks) {
+        cfg = c;
+        break;
+      }
+    const uint32_t per_iter = (uint32_t)(kCfgs[cfg].G * kCfgs[cfg].CU);
+    p.q_chunks = (p.nchunks + per_iter - 1) / per_iter * per_iter;
+    p.cand_slots = ix->cand_slots ? (uint32_t)ix->cand_slots : (uint32_t)(ix->cand_factor * p.B + 192);
+    p.cand_slots = std::max<uint32_t>(p.cand_slots, (uint32_t)p.B + 1);  // also hosts the final result list
+    p.spill_entries = (uint32_t)ix->spill_entries;
+    p.bitmap_words = (uint32_t)(((ix->capacity + 31) / 32 + 3) / 4 * 4);  // whole 16-byte groups: wide clears
+    p.ovf_cap = ix->overflow_list >= 0 ? (uint32_t)ix->overflow_list
+                                       : ((uint64_t)p.bitmap_words * 4 > (512u << 10) ? 16384u : 0u);
+    const bool full = (p.nchunks % per_iter) == 0;  // rows are whole spans: the lean FULL kernels apply
+    plan.cfg = cfg;
+    plan.full = full;
+
+    // the exact two-heap kernel: always configured (it also replays what a sorted-beam kernel hands over)
+    plan.heaps = p;
+    plan.kern = pick_kernel(ix->dtype, ix->metric, cfg, full);
+    int rc = configure_launch(ix, plan.heaps, plan.kern, MODE_HEAPS, &plan.lds, &plan.bpc);
+    if (rc) return rc;
+
+    // Sorted-beam kernel (sorted_beam.hpp): the beam as one sorted array, in registers for beams of at most 64
+    // entries ("register_beam" != 0), else in LDS; queries in which equal keys meet at a decision are searched
+    // again by the same wave with the exact two-heap code.  Same results.  "sorted_beam": 0 = never, 1 = always,
+    // 2 (default) = adaptive: used until more than a fifth of a launch's queries needed the exact search (integer
+    // data with wide beams ties everywhere), then the two-heap kernel serves that beam width on this index.
+    const bool tagged = plan.heaps.vis_tag16 != 0;
+    const bool want = ix->sorted_beam != 0 && B >= ix->sorted_beam_min && ix->capacity < (1ull << 31);
+    plan.mode = (!tagged || !want) ? MODE_HEAPS : (B <= WAVE && ix->register_beam != 0) ? MODE_SORTED_REGS : MODE_SORTED_LDS;
+    if (plan.mode != MODE_HEAPS) {
+      plan.skern = pick_sorted_kernel(ix->dtype, ix->metric, cfg, full, plan.mode == MODE_SORTED_LDS);
+      // the exact re-run's candidates heap: in LDS if that costs neither resident queries nor visited-table
+      // slots, else entirely in the slot's HBM spill area (slower for the few queries that need it)
+      SearchParams with = p, without = p;
+      without.cand_slots = 0;
+      uint32_t lds_w = 0, lds_wo = 0;
+      int bpc_w = 0, bpc_wo = 0;
+      rc = configure_launch(ix, without, plan.skern, plan.mode, &lds_wo, &bpc_wo);
+      if (rc) return rc;
+      const int rc_w = configure_launch(ix, with, plan.skern, plan.mode, &lds_w, &bpc_w);
+      const bool keep_lds = rc_w == FNV_OK && (ix->sorted_cand_lds == 1 || (ix->sorted_cand_lds == 2 && bpc_w >= bpc_wo &&
+                                                                              with.vis_slots >= without.vis_slots));
+      plan.sorted = keep_lds ? with : without;
+      plan.slds = keep_lds ? lds_w : lds_wo;
+      plan.sbpc = keep_lds ? bpc_w : bpc_wo;
+      if (!plan.sorted.vis_tag16) plan.mode = MODE_HEAPS;
+      if ((uint64_t)plan.sorted.cand_slots + plan.sorted.spill_entries < 3ull * (uint64_t)B + 256) plan.mode = MODE_HEAPS;
+    }
+    plan.B = B;
+    plan.K = K;
+    plan.capacity = ix->capacity;
+    plan.options_version = ix->options_version;
+    plan.valid = true;
+  }
+  // Adaptive choice ("sorted_beam" = 2): both kernels give the same answers; which one is faster depends on how often
+  // equal keys force the sorted-beam kernel to search a query twice (rarely on float data, often on integer-valued
+  // data with wide beams) -- so it is measured: launches of at least 2048 queries are timed by the events that bracket
+  // them anyway, harvested when a later call finds them complete, first one kernel, then the other, then the faster.
+  bool sorted = plan.mode != MODE_HEAPS;
+  bool sample = false;
+  if (sorted && ix->sorted_beam == 2) {
+    if (ix->sample_kernel >= 0 && ix->launched && hipEventQuery(ix->ev1) == hipSuccess) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ix->ev0, ix->ev1) == hipSuccess && ms > 0.f) {
+        fnv_index_s::Tuner& t = ix->tuner[ix->sample_B];
+        const float per_q = ms / (float)ix->sample_nq;
+        if (t.samples[ix->sample_kernel] == 0 || per_q < t.best[ix->sample_kernel]) t.best[ix->sample_kernel] = per_q;
+        t.samples[ix->sample_kernel]++;
+      }
+      ix->sample_kernel = -1;
+    }
+    if (nq >= 2048) {
+      fnv_index_s::Tuner& t = ix->tuner[B];
+      if (t.samples[1] < 2) sorted = true;  // two samples each (the first launch of a kernel is a cold one)
+      else if (t.samples[0] < 2) sorted = false;
+      else sorted = t.best[1] <= t.best[0] * 1.02f;
+      sample = t.samples[sorted ? 1 : 0] < 3;
+    }
+  }
+  const int bpc = sorted ? plan.sbpc : plan.bpc;
+  const uint32_t lds_bytes = sorted ? plan.slds : plan.lds;
+  const uint32_t nslots = (uint32_t)std::min<uint64_t>(nq, (uint64_t)bpc * (uint64_t)ix->num_cus);
+  const uint32_t max_slots = (uint32_t)std::min<uint64_t>(nq, (uint64_t)std::max(plan.bpc, plan.sbpc) * (uint64_t)ix->num_cus);
+
+  // ---- workspace (grown on demand; sized for whichever kernel keeps more slots resident) -------------------------
+  int rc = grow((void**)&ix->d_bitmap, &ix->bitmap_bytes, (size_t)max_slots * plan.heaps.bitmap_words * 4, true);
+  if (!rc) rc = grow((void**)&ix->d_ovf, &ix->ovf_bytes, (size_t)max_slots * plan.heaps.ovf_cap * 4);
+  if (!rc) rc = grow((void**)&ix->d_spill, &ix->spill_bytes, (size_t)max_slots * plan.heaps.spill_entries * 8);
+  if (rc) return rc;
+
+  SearchParams p = sorted ? plan.sorted : plan.heaps;
   p.labels = node_ids ? nullptr : ix->d_labels;
   p.queries = (const uint8_t*)d_queries;
   p.out_dist = d_out_dist;
@@ -588,255 +748,46 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   p.out_nhops = d_out_nhops;
   p.n_nodes = ix->n_nodes;
   p.nq = (uint32_t)nq;
-  p.M = ix->M;
-  p.dim = ix->dim;
-  p.row_bytes = ix->row_bytes;
-  p.nchunks = ix->row_bytes / 16;
-  p.K = K;
-  p.B = std::max(ef_search, K);  // Index.h:392
   // Index.h:851-861: step = max(1, N / n_init); nodes 0, step, 2*step, ... < N
   uint64_t step = ix->n_nodes / (uint64_t)num_initializations;
   if (step == 0) step = 1;
   p.scan_step = (uint32_t)step;
   p.n_scan = (uint32_t)((ix->n_nodes + step - 1) / step);
-
-  int cfg = kNumCfgs - 1;
-  for (int c = 0; c < kNumCfgs; c++)
-    if ((uint32_t)(kCfgs[c].G * kCfgs[c].CU) >= p.nchunks) {
-      cfg = c;
-      break;
-    }
-  const uint32_t per_iter = (uint32_t)(kCfgs[cfg].G * kCfgs[cfg].CU);
-  p.q_chunks = (p.nchunks + per_iter - 1) / per_iter * per_iter;
-
-  p.cand_slots = ix->cand_slots ? (uint32_t)ix->cand_slots : (uint32_t)(ix->cand_factor * p.B + 192);
-  p.cand_slots = std::max<uint32_t>(p.cand_slots, (uint32_t)p.B + 1);  // also hosts the final result list
-  p.spill_entries = (uint32_t)ix->spill_entries;
-  p.bitmap_words = (uint32_t)(((ix->capacity + 31) / 32 + 3) / 4 * 4);  // whole 16-byte groups: wide clears
-  p.ovf_cap = ix->overflow_list >= 0 ? (uint32_t)ix->overflow_list
-                                     : ((uint64_t)p.bitmap_words * 4 > (512u << 10) ? 16384u : 0u);
-
-  const bool full = (p.nchunks % per_iter) == 0;  // rows are whole spans: the lean FULL kernels apply
-  kernel_fn kern = pick_kernel(ix->dtype, ix->metric, cfg, full);
-
-  // Visited-table geometry for a table of `slots` (2^j or 3*2^j) and the LDS layout that follows from it.
-  // 16-bit tags whenever the per-bucket id range fits 14 bits: buckets = mult*2^k, t = nbits - k, need
-  // t <= 14 (mult 1) or t <= 15 (mult 3).
-  uint32_t nbits = 1;
-  while (nbits < 32 && (1ull << nbits) < ix->capacity) nbits++;
-  auto lay_out = [&](uint32_t slots) -> uint32_t {
-    const uint32_t mult = (slots % 3 == 0) ? 3u : 1u;
-    uint32_t k = 0;
-    for (uint32_t b = slots / 4 / mult; b > 1; b >>= 1) k++;
-    const bool can16 = !ix->visited_wide && ix->visited_tag_bits <= 16 && nbits <= 30 && k <= nbits && (nbits - k) <= (mult == 3 ? 15u : 14u);
-    // otherwise 64-bit buckets: three 21-bit tags (slots = 3 * 2^j) or two 32-bit tags (slots = 2^j)
-    const uint32_t w = can16 ? 16u : (slots % 3 == 0 ? 21u : 32u);
-    const uint32_t wbuckets = w == 21 ? slots / 3 : slots / 2;
-    uint32_t wk = 0;
-    for (uint32_t b = wbuckets; b > 1; b >>= 1) wk++;
-    const bool canw = !can16 && !ix->visited_wide && wk <= nbits && (nbits - wk) <= w - 2;
-    if (!can16 && !canw && mult == 3) slots = pow2_ceil(slots);  // the open-addressing table needs a power of two
-    p.vis_slots = slots;
-    p.vis_tag16 = (can16 || canw) ? 1u : 0u;
-    p.vis_w = w;
-    p.vis_mult = can16 ? mult : 1u;
-    p.vis_nmask = (uint32_t)((1ull << nbits) - 1ull);
-    p.vis_rshift = can16 ? nbits - k : (canw ? nbits - wk : 0);
-    p.vis_rmask = p.vis_tag16 ? (uint32_t)((1ull << p.vis_rshift) - 1ull) : 0;
-    p.vis_bytes = can16 ? slots * 2 : (canw ? wbuckets * 8 : slots * 4);
-    if (canw) {
-      p.vis_R = w == 21 ? (1ull | (1ull << 21) | (1ull << 42)) : (1ull | (1ull << 32));
-      p.vis_H = p.vis_R << (w - 1);
-      p.vis_Lo = p.vis_R * ((1ull << (w - 1)) - 1ull);
-    }
-    p.vis_shift = 32;
-    for (uint32_t sft = p.vis_slots; sft > 1; sft >>= 1) p.vis_shift--;
-    p.vis_limit = p.vis_slots / 4 * 3;
-
-    auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
-    uint32_t off = 0;
-    p.off_q = off;
-    off = align16(off + p.q_chunks * 16);
-    p.off_nbr = off + 8;  // heap arrays start at 16n + 8: child pairs are 16-byte aligned
-    off = align16(off + 8 + ((uint32_t)p.B + 2) * 8);
-    p.off_cand = off + 8;
-    off = align16(off + 8 + (p.cand_slots + 1) * 8);
-    p.off_vis = off;
-    off = align16(off + p.vis_bytes);
-    p.off_stage_ids = off;
-    off = align16(off + (WAVE + 1) * 4);  // + one write-only slot for lanes with nothing to stage
-    p.off_ovf = off;
-    off = align16(off + (OVF_LIST + 2) * 4);
-    return off;
-  };
-  auto resident = [&](uint32_t lds) -> int {  // query slots one CU can hold with this much LDS each
-    if (lds > 160u * 1024u) return 0;
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kern, WAVE, lds) != hipSuccess) n = 0;
-    return n;
-  };
-  // Table sizes, ascending: 256, 384, 512, 768, ...  The roomy size (visited_factor * B + 600, <= 60 % load
-  // on the reference workloads) keeps every id in LDS; but LDS is also what limits how many queries a CU
-  // keeps in flight, and a lone wave issues slowly -- below ~13 resident queries per CU the loss of
-  // latency hiding costs more than sending part of the ids to the HBM bitmap (measured: profiles/
-  // r1_visited_sizing.md).  So: the largest size <= roomy that still leaves `occupancy_target` queries
-  // per CU, but never below visited_floor slots.
-  uint32_t lds_bytes;
-  if (ix->visited_slots) {
-    lds_bytes = lay_out((uint32_t)ix->visited_slots);
-  } else {
-    const uint64_t want = std::max<uint64_t>((uint64_t)ix->visited_factor * (uint64_t)p.B + 600, 256);
-    std::vector<uint32_t> sizes;
-    for (uint32_t base = 256; base <= (1u << 15); base <<= 1) {
-      sizes.push_back(base);
-      if (base >= want) break;
-      if (base < (1u << 15)) {
-        sizes.push_back(base / 2 * 3);
-        if ((uint64_t)base / 2 * 3 >= want) break;
-      }
-    }
-    size_t pick = sizes.size() - 1;  // roomy
-    lds_bytes = lay_out(sizes[pick]);
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)std::min<uint32_t>(lds_bytes, 160u * 1024u));
-    const int target = (int)ix->occupancy_target;
-    const uint32_t roomy_tag16 = p.vis_tag16;
-    for (size_t cand = pick; cand-- > 0 && sizes[cand] >= (uint32_t)ix->visited_floor && resident(lds_bytes) < target;) {
-      const uint32_t smaller = lay_out(sizes[cand]);
-      // not a step down: the tag format lost (too few buckets for this id width), or -- wider tags per slot -- no
-      // fewer bytes than the table already chosen
-      if (p.vis_tag16 != roomy_tag16 || smaller >= lds_bytes) continue;
-      pick = cand;
-      lds_bytes = smaller;
-    }
-    lds_bytes = lay_out(sizes[pick]);
-  }
-  if (lds_bytes > 160u * 1024u)
-    return fail(FNV_ERR_INVALID, "ef_search too large for the on-chip beam state (needs " + std::to_string(lds_bytes) +
-                                     " bytes of LDS, 163840 available); lower ef_search or the *_slots options");
-
-  HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  int bpc = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, WAVE, lds_bytes));
-  if (bpc < 1) bpc = 1;
-  if (ix->blocks_per_cu > 0) bpc = std::min<int>(bpc, (int)ix->blocks_per_cu);
-  const uint32_t nslots = (uint32_t)std::min<uint64_t>(nq, (uint64_t)bpc * (uint64_t)ix->num_cus);
-
-  // "register_beam": beams of at most 64 entries run in the register-beam kernel first; it hands the queries in
-  // which equal keys met at a decision to the exact (libstdc++-replay) kernel through a redo list (fast_search.hpp).
-  // Same results.  Measured 5-8 % faster than the two-heap kernel alone on 1-byte element types (128-byte rows: the
-  // hop is instruction-bound) and 8-14 % slower on float32 rows, hence the default 2 = only for uint8 / int8.
-  const bool want_fast = ix->register_beam == 1 || (ix->register_beam == 2 && dtype_size(ix->dtype) == 1);
-  const bool fast = want_fast && p.B <= WAVE && p.vis_tag16;
-  SearchParams pf = p;
-  uint32_t lds_fast = 0, nslots_fast = 0;
-  kernel_fn fkern = nullptr;
-  if (fast) {
-    auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
-    uint32_t off = 0;
-    pf.off_q = off;
-    off = align16(off + pf.q_chunks * 16);
-    pf.off_vis = off;
-    off = align16(off + pf.vis_bytes);
-    pf.off_stage_ids = off;
-    off = align16(off + (WAVE + 1) * 4);
-    pf.off_ovf = off;
-    off = align16(off + (OVF_LIST + 2) * 4);
-    lds_fast = off;
-    fkern = pick_fast_kernel(ix->dtype, ix->metric, cfg, full);
-    HIP_TRY(hipFuncSetAttribute((const void*)fkern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast));
-    int bf = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bf, (const void*)fkern, WAVE, lds_fast));
-    if (bf < 1) bf = 1;
-    if (ix->blocks_per_cu > 0) bf = std::min<int>(bf, (int)ix->blocks_per_cu);
-    nslots_fast = (uint32_t)std::min<uint64_t>(nq, (uint64_t)bf * (uint64_t)ix->num_cus);
-  }
-  const uint32_t nslots_ws = std::max(nslots, nslots_fast);
-
-  // workspace
-  const size_t need_bitmap = (size_t)nslots_ws * p.bitmap_words * 4;
-  if (need_bitmap > ix->bitmap_bytes) {
-    if (ix->d_bitmap) HIP_TRY(hipFree(ix->d_bitmap));
-    ix->d_bitmap = nullptr;
-    ix->bitmap_bytes = 0;
-    HIP_TRY(hipMalloc(&ix->d_bitmap, need_bitmap));
-    HIP_TRY(hipMemset(ix->d_bitmap, 0, need_bitmap));
-    ix->bitmap_bytes = need_bitmap;
-  }
-  const size_t need_ovf = (size_t)nslots_ws * p.ovf_cap * 4;
-  if (need_ovf > ix->ovf_bytes) {
-    if (ix->d_ovf) HIP_TRY(hipFree(ix->d_ovf));
-    ix->d_ovf = nullptr;
-    ix->ovf_bytes = 0;
-    HIP_TRY(hipMalloc(&ix->d_ovf, need_ovf));
-    ix->ovf_bytes = need_ovf;
-  }
-  const size_t need_spill = (size_t)nslots * p.spill_entries * 8;
-  if (need_spill > ix->spill_bytes) {
-    if (ix->d_spill) HIP_TRY(hipFree(ix->d_spill));
-    ix->d_spill = nullptr;
-    ix->spill_bytes = 0;
-    HIP_TRY(hipMalloc(&ix->d_spill, need_spill));
-    ix->spill_bytes = need_spill;
-  }
   p.ovf_bitmap = ix->d_bitmap;
   p.ovf_glist = ix->d_ovf;
   p.cand_spill = ix->d_spill;
   p.dispenser = ix->d_dispenser;
   p.status = (int32_t*)(ix->d_dispenser + 1);
+  p.redo_count = ix->d_dispenser + 3;  // [3] queries searched exactly after a tie, [4..7] by reason
   p.phase_cycles = ix->d_phase;
 
-  if (fast) {
-    const size_t need_redo = (size_t)nq * 4;
-    if (need_redo > ix->redo_bytes) {
-      if (ix->d_redo) HIP_TRY(hipFree(ix->d_redo));
-      ix->d_redo = nullptr;
-      ix->redo_bytes = 0;
-      HIP_TRY(hipMalloc(&ix->d_redo, need_redo));
-      ix->redo_bytes = need_redo;
-    }
-  }
   HIP_TRY(hipMemsetAsync(ix->d_dispenser, 0, 8 * sizeof(uint32_t), stream));
   HIP_TRY(hipEventRecord(ix->ev0, stream));
   if (ix->entry_kernel) {
     // K0: one pass over the shared entry-scan nodes for the whole batch (LDS-staged), same stream
-    const size_t need_entry = (size_t)nq * 8;
-    if (need_entry > ix->entry_bytes) {
-      if (ix->d_entry) HIP_TRY(hipFree(ix->d_entry));
-      ix->d_entry = nullptr;
-      ix->entry_bytes = 0;
-      HIP_TRY(hipMalloc(&ix->d_entry, need_entry));
-      ix->entry_bytes = need_entry;
-    }
+    rc = grow((void**)&ix->d_entry, &ix->entry_bytes, (size_t)nq * 8);
+    if (rc) return rc;
     p.entry_node_out = (uint32_t*)ix->d_entry;
     p.entry_dist_out = (float*)((uint8_t*)ix->d_entry + (size_t)nq * 4);
     p.scan_tile_stride = p.row_bytes + 16;
     const uint32_t fixed = SCAN_WAVES * p.q_chunks * 16 + SCAN_QPB * 8;
     p.scan_tile_rows = std::max<uint32_t>(1, std::min<uint32_t>(p.n_scan, (64u * 1024u) / p.scan_tile_stride));
     const uint32_t scan_lds = fixed + p.scan_tile_rows * p.scan_tile_stride;
-    kernel_fn scan = pick_scan_kernel(ix->dtype, ix->metric, cfg, full);
+    kernel_fn scan = pick_scan_kernel(ix->dtype, ix->metric, plan.cfg, plan.full);
     HIP_TRY(hipFuncSetAttribute((const void*)scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
     hipLaunchKernelGGL(scan, dim3((unsigned)((nq + SCAN_QPB - 1) / SCAN_QPB)), dim3(SCAN_WAVES * WAVE), scan_lds, stream, p);
     HIP_TRY(hipGetLastError());
     p.entry_node = p.entry_node_out;
     p.entry_dist = p.entry_dist_out;
   }
-  if (fast) {
-    pf.ovf_bitmap = p.ovf_bitmap;
-    pf.ovf_glist = p.ovf_glist;
-    pf.dispenser = p.dispenser;
-    pf.status = p.status;
-    pf.entry_node = p.entry_node;
-    pf.entry_dist = p.entry_dist;
-    pf.redo_list = p.redo_list = ix->d_redo;
-    pf.redo_count = p.redo_count = ix->d_dispenser + 3;
-    hipLaunchKernelGGL(fkern, dim3(nslots_fast), dim3(WAVE), lds_fast, stream, pf);
-    HIP_TRY(hipGetLastError());
-    p.dispenser = ix->d_dispenser + 2;  // the exact kernel now walks the redo list (usually empty or short)
-  }
+  kernel_fn kern = sorted ? plan.skern : plan.kern;
+  HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipLaunchKernelGGL(kern, dim3(nslots), dim3(WAVE), lds_bytes, stream, p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ix->ev1, stream));
+  ix->sample_kernel = sample ? (sorted ? 1 : 0) : -1;
+  ix->sample_B = B;
+  ix->sample_nq = nq;
   ix->last_stream = stream;
   ix->launched = true;
   ix->geom[0] = nslots;
@@ -845,6 +796,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   ix->geom[3] = (uint64_t)bpc;
   ix->geom[4] = p.vis_slots;
   ix->geom[5] = p.cand_slots;
+  ix->geom[6] = (uint64_t)(sorted ? plan.mode : MODE_HEAPS);
   return FNV_OK;
 }
 
@@ -950,18 +902,16 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
       HIP_TRY(hipMalloc(&ix->d_out, obytes));
       ix->d_out_bytes = obytes;
     }
-    if (!ix->d_head) {
-      HIP_TRY(hipMalloc(&ix->d_head, ix->capacity * 4));
-      HIP_TRY(hipMemset(ix->d_head, 0xFF, ix->capacity * 4));
-    }
-    const size_t wb = 16 + 2 * count * (size_t)keep * 4;
-    if (wb > ix->wirebuf_bytes) {
-      if (ix->d_wirebuf) HIP_TRY(hipFree(ix->d_wirebuf));
-      ix->d_wirebuf = nullptr;
-      ix->wirebuf_bytes = 0;
-      HIP_TRY(hipMalloc(&ix->d_wirebuf, wb));
-      ix->wirebuf_bytes = wb;
-    }
+  }
+  const size_t nreq = (size_t)count * keep;
+  size_t sort_bytes = 0;
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                             (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)nreq, 0, 32, ix->stream));
+  const size_t req_bytes = (nreq * 4 + 255) & ~(size_t)255;
+  {
+    std::lock_guard<std::mutex> lock(ix->mu);
+    int rcg = grow(&ix->d_wirebuf, &ix->wirebuf_bytes, 4 * req_bytes + sort_bytes + 256);
+    if (rcg) return rcg;
   }
   uint8_t* o = (uint8_t*)ix->d_out;
   // the new nodes' vectors are the queries (Index.h:371: beamSearch(data, entry, ef_construction)); dense rows
@@ -974,12 +924,17 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
   std::lock_guard<std::mutex> lock(ix->mu);
   WireParams w;
   memset(&w, 0, sizeof(w));
+  uint8_t* wb = (uint8_t*)ix->d_wirebuf;
+  uint32_t* req_target = (uint32_t*)wb;
+  uint32_t* req_index = (uint32_t*)(wb + req_bytes);
+  uint32_t* sorted_target = (uint32_t*)(wb + 2 * req_bytes);
+  uint32_t* sorted_req = (uint32_t*)(wb + 3 * req_bytes);
+  void* sort_tmp = wb + 4 * req_bytes;
   w.vectors = ix->d_vectors;
   w.links = ix->d_links;
-  w.head = ix->d_head;
-  w.n_targets = (uint32_t*)ix->d_wirebuf;
-  w.req_next = (int32_t*)((uint8_t*)ix->d_wirebuf + 16);
-  w.targets = (uint32_t*)(w.req_next + count * (size_t)keep);
+  w.req_target = req_target;
+  w.sorted_target = sorted_target;
+  w.sorted_req = sorted_req;
   w.beam_dist = (const float*)(o + o_dist);
   w.beam_ids = (const int32_t*)(o + o_lab);
   w.beam_count = (const int32_t*)(o + o_cnt);
@@ -1018,19 +973,25 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
   if (lds_bytes > 160u * 1024u) return fail(FNV_ERR_INVALID, "ef_construction too large for the on-chip wiring state");
   wire_fn kernels[2] = {pick_wire_kernel(ix->dtype, ix->metric, cfg, full),
                         pick_connect_kernel(ix->dtype, ix->metric, cfg, full)};
-  HIP_TRY(hipMemsetAsync(ix->d_wirebuf, 0, 16, ix->stream));
   for (int phase = 0; phase < 2; phase++) {
     wire_fn kern = kernels[phase];
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     int bpc = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, WAVE, lds_bytes));
     if (bpc < 1) bpc = 1;
-    // select: one unit of work per new node; connect: per distinct target (at most count * keep, known on the device)
-    const uint64_t units = phase == 0 ? count : count * (uint64_t)keep;
+    // select: one unit of work per new node; connect: per 64 positions of the sorted request list
+    const uint64_t units = phase == 0 ? count : (nreq + WAVE - 1) / WAVE;
     const uint32_t nslots = (uint32_t)std::min<uint64_t>(units, (uint64_t)bpc * (uint64_t)ix->num_cus);
     HIP_TRY(hipMemsetAsync(ix->d_dispenser, 0, sizeof(uint32_t), ix->stream));
     hipLaunchKernelGGL(kern, dim3(nslots), dim3(WAVE), lds_bytes, ix->stream, w);
     HIP_TRY(hipGetLastError());
+    if (phase == 0) {  // group the batch's back-link requests by target (stable: insertion order within a target)
+      hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((nreq + 255) / 256)), dim3(256), 0, ix->stream, req_index, (uint32_t)nreq);
+      HIP_TRY(hipGetLastError());
+      size_t tmp = sort_bytes;
+      HIP_TRY(hipcub::DeviceRadixSort::SortPairs(sort_tmp, tmp, (const uint32_t*)req_target, sorted_target,
+                                                 (const uint32_t*)req_index, sorted_req, (int)nreq, 0, 32, ix->stream));
+    }
   }
   std::vector<uint64_t> nd;
   if (evals_out) {
@@ -1104,9 +1065,9 @@ int fnv_last_replayed_queries(fnv_index_t ix, uint64_t out[5]) {
   return FNV_OK;
 }
 
-int fnv_last_launch_geometry(fnv_index_t ix, uint64_t geom[6]) {
+int fnv_last_launch_geometry(fnv_index_t ix, uint64_t geom[7]) {
   if (!ix || !geom) return fail(FNV_ERR_INVALID, "null argument");
-  for (int i = 0; i < 6; i++) geom[i] = ix->geom[i];
+  for (int i = 0; i < 7; i++) geom[i] = ix->geom[i];
   return FNV_OK;
 }
 

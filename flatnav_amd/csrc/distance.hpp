@@ -43,7 +43,10 @@ template <int METRIC>
 struct Dist<float, METRIC> {
   // two partial sums per lane so subtract and multiply-add issue as packed f32 (v_pk_add_f32 / v_pk_fma_f32)
   typedef f32x2 acc_t;
+  typedef int qacc_t;  // unused for float rows
   static __device__ __forceinline__ f32x2 zero() { return f32x2{0.f, 0.f}; }
+  static __device__ __forceinline__ int qzero() { return 0; }
+  static __device__ __forceinline__ int qchunk(int q, const uint4&) { return q; }
   static __device__ __forceinline__ f32x2 chunk(f32x2 acc, const uint4& x, const uint4& y) {
     const f32x2 x0 = {__uint_as_float(x.x), __uint_as_float(x.y)}, x1 = {__uint_as_float(x.z), __uint_as_float(x.w)};
     const f32x2 y0 = {__uint_as_float(y.x), __uint_as_float(y.y)}, y1 = {__uint_as_float(y.z), __uint_as_float(y.w)};
@@ -57,36 +60,50 @@ struct Dist<float, METRIC> {
     }
     return acc;
   }
-  static __device__ __forceinline__ float lane_sum(f32x2 a) { return a.x + a.y; }
+  static __device__ __forceinline__ float lane_sum(f32x2 a, int) { return a.x + a.y; }
   static __device__ __forceinline__ float finish(float s) { return METRIC == FNV_METRIC_L2 ? s : 1.0f - s; }
 };
 
+// 1-byte element types: four products per instruction (v_dot4_u32_u8 / v_dot4_i32_i8), exact int32 accumulation --
+// the arithmetic of the reference's AVX-512 uint8 path (SquaredL2SimdExtensions.h:32-76: widen, multiply, add into
+// 32-bit lanes) and, while sums stay below 2^24, of its scalar float loops (L2DistanceDispatcher.h:10-17,
+// IPDistanceDispatcher.h:79-93).  L2 is evaluated as  sum x^2 - 2 sum xy + sum y^2 : three dot products, every one
+// exact, so the value is the same integer as sum (x-y)^2.  sum x^2 over a lane's chunks is shared by all PU passes.
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
 template <typename T, int METRIC>
 struct DistInt {
-  typedef int acc_t;
-  static __device__ __forceinline__ int zero() { return 0; }
-  static __device__ __forceinline__ int lane_sum(int a) { return a; }
-  static __device__ __forceinline__ int elem(uint32_t w, int k) {
-    if (sizeof(T) == 1 && T(-1) < T(0)) return (int)(int8_t)(w >> (8 * k));
-    return (int)((w >> (8 * k)) & 0xffu);
+  static constexpr bool SIGNED = T(-1) < T(0);
+  typedef i32x2 acc_t;  // {sum x*y, sum y*y}
+  typedef int qacc_t;   // sum x*x
+  static __device__ __forceinline__ i32x2 zero() { return i32x2{0, 0}; }
+  static __device__ __forceinline__ int qzero() { return 0; }
+  static __device__ __forceinline__ int dot(uint32_t a, uint32_t b, int c) {
+    if (SIGNED) return __builtin_amdgcn_sdot4((int)a, (int)b, c, false);
+    return (int)__builtin_amdgcn_udot4(a, b, (uint32_t)c, false);
   }
-  static __device__ __forceinline__ int chunk(int acc, const uint4& x, const uint4& y) {
-    const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
-    const uint32_t ys[4] = {y.x, y.y, y.z, y.w};
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        int a = elem(xs[i], k), b = elem(ys[i], k);
-        if (METRIC == FNV_METRIC_L2) {
-          int t = a - b;
-          acc += t * t;
-        } else {
-          acc += a * b;
-        }
-      }
+  static __device__ __forceinline__ int qchunk(int q, const uint4& x) {
+    if (METRIC != FNV_METRIC_L2) return q;
+    q = dot(x.x, x.x, q);
+    q = dot(x.y, x.y, q);
+    q = dot(x.z, x.z, q);
+    return dot(x.w, x.w, q);
+  }
+  static __device__ __forceinline__ i32x2 chunk(i32x2 acc, const uint4& x, const uint4& y) {
+    acc.x = dot(x.x, y.x, acc.x);
+    acc.x = dot(x.y, y.y, acc.x);
+    acc.x = dot(x.z, y.z, acc.x);
+    acc.x = dot(x.w, y.w, acc.x);
+    if (METRIC == FNV_METRIC_L2) {
+      acc.y = dot(y.x, y.x, acc.y);
+      acc.y = dot(y.y, y.y, acc.y);
+      acc.y = dot(y.z, y.z, acc.y);
+      acc.y = dot(y.w, y.w, acc.y);
     }
     return acc;
+  }
+  static __device__ __forceinline__ int lane_sum(i32x2 a, int q) {
+    return METRIC == FNV_METRIC_L2 ? q + a.y - 2 * a.x : a.x;
   }
   static __device__ __forceinline__ float finish(int s) {
     return METRIC == FNV_METRIC_L2 ? (float)s : 1.0f - (float)s;
@@ -116,6 +133,7 @@ __device__ __forceinline__ void batch_dists(const uint8_t* rows, uint32_t row_st
   typedef typename D::acc_t acc_t;
   const int g = lane % G;
   acc_t acc[PU];
+  typename D::qacc_t qacc = D::qzero();  // query-only term of the lane's chunks (1-byte L2: sum x^2)
   const uint8_t* rowp[PU];
 #pragma unroll
   for (int pu = 0; pu < PU; pu++) {
@@ -140,6 +158,7 @@ __device__ __forceinline__ void batch_dists(const uint8_t* rows, uint32_t row_st
 #pragma unroll
       for (int cu = 0; cu < CU; cu++) {
         const uint4 x = qlds[c0 + cu * G + g];
+        qacc = D::qchunk(qacc, x);
 #pragma unroll
         for (int pu = 0; pu < PU; pu++)
           if (pu < npass) acc[pu] = D::chunk(acc[pu], x, y[pu][cu]);
@@ -164,6 +183,7 @@ __device__ __forceinline__ void batch_dists(const uint8_t* rows, uint32_t row_st
       const int c = c0 + cu * G + g;
       const uint4 x = qlds[c];  // zero beyond the row (q_chunks covers the last c0 block)
       const bool in_row = c < nchunks;
+      qacc = D::qchunk(qacc, x);
 #pragma unroll
       for (int pu = 0; pu < PU; pu++) {
         if (pu < npass) {
@@ -178,7 +198,7 @@ __device__ __forceinline__ void batch_dists(const uint8_t* rows, uint32_t row_st
 #pragma unroll
   for (int pu = 0; pu < PU; pu++) {
     out[pu] = 0.f;
-    if (pu < npass) out[pu] = D::finish(group_sum<G>(D::lane_sum(acc[pu])));
+    if (pu < npass) out[pu] = D::finish(group_sum<G>(D::lane_sum(acc[pu], qacc)));
   }
 }
 

@@ -90,7 +90,7 @@ struct PhaseTimer {
 #endif
 #define PH_DECL PhaseTimer ph; ph.start();
 #define PH_MARK(i) do { ph.mark(i); ISA_MARK("phase" #i); } while (0)
-#define PH_FLUSH ph.flush(p.phase_cycles, lane)
+#define PH_FLUSH ph.flush(cold_args()->phase_cycles, lane)
 
 // ---------------------------------------------------------------------------------------------
 // Wave-cooperative forms of the two libstdc++ heap operations (same element moves as

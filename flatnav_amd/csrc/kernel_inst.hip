@@ -1,0 +1,60 @@
+// kernel_inst.hip -- one compilation = the instantiations of ONE kernel family for ONE (element type, metric):
+//   hipcc -c -DFNV_INST_T=float -DFNV_INST_TAG=f32 -DFNV_INST_METRIC=0 -DFNV_INST_MTAG=l2 -DFNV_INST_FAMILY=2 ...
+// families: 0 exact two-heap kernel + entry scan, 1 sorted beam in registers, 2 sorted beam in LDS, 3 wiring kernels.
+// flatnav_amd/build.py compiles the 24 combinations in parallel and links them with beam_search.hip.
+#include <hip/hip_runtime.h>
+
+#include "kernel_table.h"
+#include "kernels.hpp"
+#include "sorted_beam.hpp"
+#include "wire.hpp"
+
+#define FNV_CAT_(a, b, c, d, e) a##b##c##d##e
+#define FNV_CAT(a, b, c, d, e) FNV_CAT_(a, b, c, d, e)
+#define FNV_FILLER(family) FNV_CAT(fill_, family, FNV_INST_TAG, _, FNV_INST_MTAG)
+
+namespace fnv_dev {
+
+typedef FNV_INST_T T;
+constexpr int METRIC = FNV_INST_METRIC;
+
+// ROW(slot, kernel template, extra template arguments...) fills slot[cfg][full] for the six row configurations
+#define FNV_ROW(slot, K, ...)                                          \
+  slot[0][FULL] = K<T, METRIC, 8, 1, FULL __VA_ARGS__>;                \
+  slot[1][FULL] = K<T, METRIC, 8, 2, FULL __VA_ARGS__>;                \
+  slot[2][FULL] = K<T, METRIC, 8, 4, FULL __VA_ARGS__>;                \
+  slot[3][FULL] = K<T, METRIC, 16, 4, FULL __VA_ARGS__>;               \
+  slot[4][FULL] = K<T, METRIC, 32, 4, FULL __VA_ARGS__>;               \
+  slot[5][FULL] = K<T, METRIC, 64, 4, FULL __VA_ARGS__>;
+
+template <bool FULL>
+static void fill_rows(KernelTable& t) {
+#if FNV_INST_FAMILY == 0
+  FNV_ROW(t.exact, beam_search_kernel)
+  FNV_ROW(t.scan, entry_scan_kernel)
+#elif FNV_INST_FAMILY == 1
+#define FNV_COMMA_FALSE , false
+  FNV_ROW(t.sorted_regs, beam_search_sorted_kernel, FNV_COMMA_FALSE)
+#elif FNV_INST_FAMILY == 2
+#define FNV_COMMA_TRUE , true
+  FNV_ROW(t.sorted_lds, beam_search_sorted_kernel, FNV_COMMA_TRUE)
+#else
+  FNV_ROW(t.select, wire_select_kernel)
+  FNV_ROW(t.connect, wire_connect_kernel)
+#endif
+}
+
+#if FNV_INST_FAMILY == 0
+void FNV_CAT(fill_exact_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
+#elif FNV_INST_FAMILY == 1
+void FNV_CAT(fill_sorted_regs_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
+#elif FNV_INST_FAMILY == 2
+void FNV_CAT(fill_sorted_lds_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
+#else
+void FNV_CAT(fill_wire_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
+#endif
+  fill_rows<false>(t);
+  fill_rows<true>(t);
+}
+
+}  // namespace fnv_dev

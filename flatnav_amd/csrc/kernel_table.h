@@ -1,0 +1,44 @@
+// kernel_table.h -- part of the gfx950 search engine: how the host code finds a kernel instantiation.
+// Every kernel is a template over <element type, metric, G lanes per vector, CU loads per lane, FULL rows>; the
+// instantiations are compiled in separate translation units (kernel_inst.hip, once per element type x metric x
+// kernel family, in parallel -- one unit with all of them takes a quarter of an hour) and registered here.
+#pragma once
+#include "search_params.h"
+#include "wire.hpp"
+
+namespace fnv_dev {
+
+typedef void (*kernel_fn)(const SearchParams);
+typedef void (*wire_fn)(const WireParams);
+
+// chunks covered per inner iteration = G*CU: 8,16,32,64,128,256 (128 B ... 4 KiB of a row)
+struct KernelCfg {
+  int G, CU;
+};
+constexpr KernelCfg kCfgs[] = {{8, 1}, {8, 2}, {8, 4}, {16, 4}, {32, 4}, {64, 4}};
+constexpr int kNumCfgs = 6;
+
+// All kernels for one (element type, metric): [row configuration][FULL rows].
+struct KernelTable {
+  kernel_fn exact[kNumCfgs][2];        // beam_search_kernel (two heaps, libstdc++-exact)
+  kernel_fn scan[kNumCfgs][2];         // entry_scan_kernel (K0)
+  kernel_fn sorted_regs[kNumCfgs][2];  // beam_search_sorted_kernel, beam in registers
+  kernel_fn sorted_lds[kNumCfgs][2];   // beam_search_sorted_kernel, beam in LDS
+  wire_fn select[kNumCfgs][2];         // wire_select_kernel
+  wire_fn connect[kNumCfgs][2];        // wire_connect_kernel
+};
+
+// X(element type, type tag, metric ordinal, metric tag)
+#define FNV_FOR_EACH_TYPE_METRIC(X) \
+  X(float, f32, 0, l2) X(float, f32, 1, ip) X(uint8_t, u8, 0, l2) X(uint8_t, u8, 1, ip) X(int8_t, i8, 0, l2) X(int8_t, i8, 1, ip)
+
+// one filler per kernel family and (type, metric), each defined by one compilation of kernel_inst.hip
+#define FNV_DECLARE_FILLERS(T, tag, M, mtag)             \
+  void fill_exact_##tag##_##mtag(KernelTable& t);        \
+  void fill_sorted_regs_##tag##_##mtag(KernelTable& t);  \
+  void fill_sorted_lds_##tag##_##mtag(KernelTable& t);   \
+  void fill_wire_##tag##_##mtag(KernelTable& t);
+FNV_FOR_EACH_TYPE_METRIC(FNV_DECLARE_FILLERS)
+#undef FNV_DECLARE_FILLERS
+
+}  // namespace fnv_dev

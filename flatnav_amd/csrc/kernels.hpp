@@ -1,5 +1,5 @@
 // kernels.hpp -- part of the gfx950 search engine (device code; included only by beam_search.hip).
-// Entry-point scan, the beam-search kernel, the K0 batch kernel, developer micro-benchmark, AoS->SoA re-layout.
+// Entry-point scan, the K0 batch kernel, the exact (two-heap) search of one query and its kernel.
 #pragma once
 #include "distance.hpp"
 #include "heaps.hpp"
@@ -51,25 +51,12 @@ __device__ __forceinline__ void wave_argmin(float& best_d, uint32_t& best_j) {
   }
 }
 
-// In-kernel variant (used when the batch kernel is switched off): scan straight from HBM / L2.
-template <typename T, int METRIC, int G, int CU, bool FULL>
-__device__ __forceinline__ uint32_t scan_entry_points(const SearchParams& p, const uint4* qlds, int lane, float& best_d) {
-  best_d = std::numeric_limits<float>::max();
-  uint32_t best_j = 0;
-  scan_rows<T, METRIC, G, CU, FULL>(p.vectors, p.row_bytes, p.scan_step, (int)p.nchunks, qlds, p.n_scan, 0u, lane,
-                                    best_d, best_j);
-  wave_argmin(best_d, best_j);
-  return best_j * p.scan_step;
-}
-
 // ---------------------------------------------------------------------------------------------
 // K0: entry points for the whole batch.  Every query scans the SAME ceil(N/step) nodes, so a workgroup
 // (4 waves) stages them once in LDS (tiles of scan_tile_rows rows, row stride padded by 16 bytes against
 // bank conflicts) and runs SCAN_QPB queries against the tile; distances use the very same batch_dists code
 // as the search kernel, so entry_dist equals what the search kernel would have computed, bit for bit.
 // ---------------------------------------------------------------------------------------------
-constexpr int SCAN_WAVES = 4;
-constexpr int SCAN_QPB = 32;
 
 template <typename T, int METRIC, int G, int CU, bool FULL>
 __global__ __launch_bounds__(SCAN_WAVES* WAVE) void entry_scan_kernel(const SearchParams p) {
@@ -119,385 +106,358 @@ __global__ __launch_bounds__(SCAN_WAVES* WAVE) void entry_scan_kernel(const Sear
   }
 }
 
+// Per-query prologue / epilogue pieces shared by the search kernels (cold: once per query, so they read their
+// parameters from the kernel-argument segment instead of keeping them in scalar registers -- see cold_args()).
+__device__ __forceinline__ void reset_visited(uint32_t* vis, uint32_t* ovf_list, bool tagged, int lane) {
+  uint4* v4 = reinterpret_cast<uint4*>(vis);
+  const uint32_t fill = tagged ? 0u : EMPTY_ID;
+  const uint32_t n16 = cold_args()->vis_bytes / 16;
+  for (uint32_t i = lane; i < n16; i += WAVE) v4[i] = make_uint4(fill, fill, fill, fill);
+  if (lane == 0) ovf_list[0] = 0u;
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_query(uint4* qlds, uint32_t* vis, uint32_t* ovf_list, int qi, bool tagged, int lane) {
+  ColdArgs c = cold_args();
+  const uint32_t dim = c->dim;
+  const T* qsrc = reinterpret_cast<const T*>(c->queries) + (uint64_t)qi * dim;
+  T* qdst = reinterpret_cast<T*>(qlds);
+  const int padded = (int)(c->q_chunks * 16u / sizeof(T));
+  for (int i = lane; i < padded; i += WAVE) qdst[i] = i < (int)dim ? qsrc[i] : T(0);
+  reset_visited(vis, ovf_list, tagged, lane);
+}
+
+// Give the slot's HBM visited bitmap back zeroed: word by word while every id that went there is on record (the
+// first OVF_LIST in LDS, then ovf_cap more in the slot's HBM list), else the whole bitmap with 16-byte stores.
+__device__ __forceinline__ void clear_spill_bitmap(uint32_t* bitmap, const uint32_t* ovf_list, const uint32_t* ovf_glist,
+                                                   bool tagged, int lane) {
+  ColdArgs c = cold_args();
+  __threadfence();
+  const uint32_t listed = ovf_list[0];
+  if (tagged && listed <= OVF_LIST + c->ovf_cap) {
+    if ((uint32_t)lane < min(listed, OVF_LIST)) bitmap[ovf_list[1 + lane] >> 5] = 0u;
+    for (uint32_t i = OVF_LIST + lane; i < listed; i += WAVE) bitmap[ovf_glist[i - OVF_LIST] >> 5] = 0u;
+  } else {
+    uint4* b4 = reinterpret_cast<uint4*>(bitmap);
+    const uint32_t n16 = c->bitmap_words / 4;
+    for (uint32_t i = lane; i < n16; i += WAVE) b4[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __threadfence();
+}
+
+// Next query of this slot (-1: none left) from the launch's atomic dispenser.
+__device__ __forceinline__ int next_query(int lane) {
+  ColdArgs c = cold_args();
+  int qi = 0;
+  if (lane == 0) qi = (int)atomicAdd(c->dispenser, 1u);
+  qi = rfl(qi);
+  return (uint32_t)qi >= c->nq ? -1 : qi;
+}
+
+// Entry point of query qi and its distance: from the batch kernel K0 if it ran, else the in-kernel scan.
 template <typename T, int METRIC, int G, int CU, bool FULL>
-__global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kernel(const SearchParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x;
-  uint4* qlds = reinterpret_cast<uint4*>(smem + p.off_q);
-  LdsHeap nbr{reinterpret_cast<unsigned long long*>(smem + p.off_nbr)};
-  LdsHeap cand{reinterpret_cast<unsigned long long*>(smem + p.off_cand)};  // while everything fits in LDS
-  CandHeap cand_big{reinterpret_cast<unsigned long long*>(smem + p.off_cand),
-                    p.cand_spill + (uint64_t)blockIdx.x * p.spill_entries, (int)p.cand_slots};
-  uint32_t* vis = reinterpret_cast<uint32_t*>(smem + p.off_vis);
-  uint32_t* stage_ids = reinterpret_cast<uint32_t*>(smem + p.off_stage_ids);
-  uint32_t* bitmap = p.ovf_bitmap + (uint64_t)blockIdx.x * p.bitmap_words;
-  uint32_t* ovf_list = reinterpret_cast<uint32_t*>(smem + p.off_ovf);
-  uint32_t* ovf_glist = p.ovf_glist + (uint64_t)blockIdx.x * p.ovf_cap;
-  const uint32_t vis_mask = p.vis_slots - 1;
-  const int B = p.B;
-  const int K = p.K;
-  const int M = (int)p.M;
+__device__ __forceinline__ uint32_t entry_point(const uint8_t* vectors, uint32_t row_bytes, int nchunks, const uint4* qlds,
+                                                int qi, int lane, float& best_d) {
+  ColdArgs c = cold_args();
+  const uint32_t* en = c->entry_node;
+  if (en) {
+    best_d = rfl(c->entry_dist[qi]);
+    return (uint32_t)rfl((int)en[qi]);
+  }
+  best_d = std::numeric_limits<float>::max();
+  uint32_t best_j = 0;
+  const uint32_t step = c->scan_step;
+  scan_rows<T, METRIC, G, CU, FULL>(vectors, row_bytes, step, nchunks, qlds, c->n_scan, 0u, lane, best_d, best_j);
+  wave_argmin(best_d, best_j);
+  return best_j * step;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The exact search of ONE query (Index.h:606-707 + :393-408): the reference's two binary heaps moved with
+// libstdc++'s element moves, link-order admissions, result tail.  Called by beam_search_kernel for every query
+// and by beam_search_sorted_kernel for the queries in which equal keys met at a decision.
+// Expects the query staged in qlds, the visited table reset, entry / best_d chosen.
+// ---------------------------------------------------------------------------------------------
+struct ExactCtx {
+  const uint8_t* vectors;
+  const uint32_t* links;
+  uint32_t row_bytes;
+  int nchunks, B, M;
+  int cand_slots;  // entries of the candidates heap that live in LDS (0: the whole heap is in the HBM spill area)
+  bool tagged;
+  VisGeom vg;
+  uint4* qlds;
+  unsigned long long* nbr;   // LDS, B + 2 entries, at 16n + 8
+  unsigned long long* cand;  // LDS, cand_slots + 1 entries, at 16n + 8 (unused when cand_slots == 0)
+  uint32_t* vis;
+  uint32_t* stage_ids;
+  uint32_t* ovf_list;
+};
+
+template <typename T, int METRIC, int G, int CU, bool FULL>
+__device__ __forceinline__ void exact_query(const ExactCtx& x, int qi, uint32_t entry, float best_d, int lane,
+                                            PhaseTimer& ph) {
+  const uint8_t* const vectors = x.vectors;
+  const uint32_t* const links = x.links;
+  const uint32_t row_bytes = x.row_bytes;
+  const int nchunks = x.nchunks, B = x.B, M = x.M, cand_slots = x.cand_slots;
+  const bool tagged = x.tagged;
+  const VisGeom vg = x.vg;
+  uint4* const qlds = x.qlds;
+  uint32_t* const vis = x.vis;
+  uint32_t* const stage_ids = x.stage_ids;
+  uint32_t* const ovf_list = x.ovf_list;
+  LdsHeap nbr{x.nbr};
+  LdsHeap cand{x.cand};  // while everything fits in LDS
+  uint32_t* const bitmap = cold_args()->ovf_bitmap + (uint64_t)blockIdx.x * cold_args()->bitmap_words;
+  uint32_t* const ovf_glist = cold_args()->ovf_glist + (uint64_t)blockIdx.x * cold_args()->ovf_cap;
+  unsigned long long* const spill = cold_args()->cand_spill + (uint64_t)blockIdx.x * cold_args()->spill_entries;
+
+  int nbr_n = 1, cand_n = 1;
+  float max_dist = best_d;  // == distance(query, entry): same arithmetic, same bits
+  if (lane == 0) {
+    CandHeap c0{cand.p, spill, cand_slots};
+    c0.set(0, fnv_stl::Entry{-best_d, entry});
+    nbr.set(0, fnv_stl::Entry{best_d, entry});
+  }
+  uint32_t vis_count = 1;
+  bool ovf = false;       // 32-bit table: switched to the bitmap; tagged: some id went to the bitmap
+  if (!tagged) {
+    if (lane == 0) visited_insert_lds(vis, cold_args()->vis_slots - 1, cold_args()->vis_shift, entry);
+  } else if (vg.w == 16) {
+    visited_insert_tag16(vis, vg, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
+  } else {
+    visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), vg, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
+  }
+  ovf = __ballot(ovf) != 0ull;
+  int err = ST_OK;
+  uint32_t n_dist = 0, n_hops = 0;
+  if (cand_slots == 0) __threadfence_block();
+  __syncthreads();
 
   while (true) {
-    int qi = 0;
-    if (lane == 0) qi = (int)atomicAdd(p.dispenser, 1u);
-    qi = rfl(qi);
-    if (p.redo_list) {  // second launch: only the queries the register-beam kernel handed over
-      if ((uint32_t)qi >= *p.redo_count) break;
-      qi = (int)p.redo_list[qi];
-    } else if ((uint32_t)qi >= p.nq) {
-      break;
+    if (cand_n <= 0) break;
+    fnv_stl::Entry ctop;
+    if (cand_slots > 0) ctop = cand.get(0);  // same address in every lane: LDS broadcast
+    else ctop = unpack(spill[0]);
+    const float ctop_d = -rfl(ctop.key);
+    if (ctop_d > max_dist && nbr_n >= B) break;  // Index.h:630
+    const int node = rfl((int)ctop.val);
+    // issue the link-row load now; the cooperative pop below hides most of its HBM latency
+    uint32_t row_id = EMPTY_ID;
+    if (lane < M) row_id = links[(uint64_t)(uint32_t)node * (uint32_t)M + lane];
+    if (cand_n <= cand_slots) {
+      coop_pop<false>(cand, cand_n, lane, ph, 8);
+    } else {  // part of the heap lives in the HBM spill area
+      CandHeap cand_big{cand.p, spill, cand_slots};
+      __threadfence_block();
+      coop_pop<false>(cand_big, cand_n, lane, ph, 8);
+      __threadfence_block();
     }
-    PH_DECL
+    cand_n--;
+    n_hops++;
+    PH_MARK(2);
 
-    // ---- stage the query (zero padded) and reset the visited table --------------------------
-    {
-      const T* qsrc = reinterpret_cast<const T*>(p.queries) + (uint64_t)qi * p.dim;
-      T* qdst = reinterpret_cast<T*>(qlds);
-      const int padded = (int)(p.q_chunks * 16u / sizeof(T));
-      for (int i = lane; i < padded; i += WAVE) qdst[i] = i < (int)p.dim ? qsrc[i] : T(0);
-      uint4* v4 = reinterpret_cast<uint4*>(vis);
-      const uint32_t fill = p.vis_tag16 ? 0u : EMPTY_ID;
-      for (uint32_t i = lane; i < p.vis_bytes / 16; i += WAVE) v4[i] = make_uint4(fill, fill, fill, fill);
-      if (lane == 0) ovf_list[0] = 0u;
-    }
-    __syncthreads();
-    PH_MARK(0);
-
-    // ---- entry-point selection (Index.h:845-870): argmin over nodes 0, s, 2s, ... -----------
-    float best_d;
-    uint32_t entry;
-    if (p.entry_node) {  // K0 ran: entry point and its distance were computed for the whole batch
-      best_d = rfl(p.entry_dist[qi]);
-      entry = (uint32_t)rfl((int)p.entry_node[qi]);
-    } else {
-      entry = scan_entry_points<T, METRIC, G, CU, FULL>(p, qlds, lane, best_d);
-    }
-    PH_MARK(1);
-
-    // ---- beam search (Index.h:606-707) -------------------------------------------------------
-    int nbr_n = 1, cand_n = 1;
-    float max_dist = best_d;  // == distance(query, entry): same arithmetic, same bits
-    if (lane == 0) {
-      cand.set(0, fnv_stl::Entry{-best_d, entry});
-      nbr.set(0, fnv_stl::Entry{best_d, entry});
-    }
-    uint32_t vis_count = 1;
-    bool ovf = false;       // 32-bit table: switched to the bitmap; tag16: some id went to the bitmap
-    if (lane == 0) {
-      if (!p.vis_tag16) visited_insert_lds(vis, vis_mask, p.vis_shift, entry);
-    }
-    if (p.vis_tag16) {
-      if (p.vis_w == 16) visited_insert_tag16(vis, p, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
-      else visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), p, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
-    }
-    ovf = __ballot(ovf) != 0ull;
-    int err = ST_OK;
-    uint32_t n_dist = 0, n_hops = 0;
-    __syncthreads();
-
-    while (true) {
-      if (cand_n <= 0) break;
-      const fnv_stl::Entry ctop = cand.get(0);  // same address in every lane: LDS broadcast
-      const float ctop_d = -rfl(ctop.key);
-      if (ctop_d > max_dist && nbr_n >= B) break;  // Index.h:630
-      const int node = rfl((int)ctop.val);
-      // issue the link-row load now; the cooperative pop below hides most of its HBM latency
-      uint32_t row_id = EMPTY_ID;
-      if (lane < M) row_id = p.links[(uint64_t)(uint32_t)node * p.M + lane];
-      if (cand_n <= (int)p.cand_slots) {
-        coop_pop<false>(cand, cand_n, lane, ph, 8);
-      } else {  // part of the heap lives in the HBM spill area
-        __threadfence_block();
-        coop_pop<false>(cand_big, cand_n, lane, ph, 8);
-        __threadfence_block();
-      }
-      cand_n--;
-      n_hops++;
-      PH_MARK(2);
-
-      for (int m0 = 0; m0 < M; m0 += WAVE) {
-        if (!p.vis_tag16 && !ovf && vis_count + WAVE > p.vis_limit) ovf = true;
-        const bool act = m0 + lane < M;
-        uint32_t id = row_id;
-        if (m0 > 0) id = act ? p.links[(uint64_t)(uint32_t)node * p.M + m0 + lane] : EMPTY_ID;
-        PH_MARK(3);
-        bool isnew = false;
-        if (p.vis_tag16) {
-          if (p.vis_w == 16) isnew = visited_insert_tag16(vis, p, act, id, bitmap, ovf_list, ovf_glist, ovf);
-          else isnew = visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), p, act, id, bitmap, ovf_list, ovf_glist, ovf);
-        } else if (act) {
+    for (int m0 = 0; m0 < M; m0 += WAVE) {
+      const bool act = m0 + lane < M;
+      uint32_t id = row_id;
+      if (m0 > 0) id = act ? links[(uint64_t)(uint32_t)node * (uint32_t)M + m0 + lane] : EMPTY_ID;
+      PH_MARK(3);
+      bool isnew = false;
+      if (tagged) {
+        if (vg.w == 16) isnew = visited_insert_tag16(vis, vg, act, id, bitmap, ovf_list, ovf_glist, ovf);
+        else isnew = visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), vg, act, id, bitmap, ovf_list, ovf_glist, ovf);
+      } else {  // 32-bit open addressing ("visited_wide", tests): hands over to the bitmap at 3/4 load
+        const uint32_t vis_mask = cold_args()->vis_slots - 1, vis_shift = cold_args()->vis_shift;
+        if (!ovf && vis_count + WAVE > cold_args()->vis_limit) ovf = true;
+        if (act) {
           if (!ovf) {
-            isnew = visited_insert_lds(vis, vis_mask, p.vis_shift, id);
-          } else if (!visited_lookup_lds(vis, vis_mask, p.vis_shift, id)) {
+            isnew = visited_insert_lds(vis, vis_mask, vis_shift, id);
+          } else if (!visited_lookup_lds(vis, vis_mask, vis_shift, id)) {
             uint32_t bit = 1u << (id & 31);
             uint32_t old = atomicOr(&bitmap[id >> 5], bit);
             isnew = !(old & bit);
           }
         }
-        ovf = __ballot(ovf) != 0ull;  // wave-uniform
-        const unsigned long long newmask = __ballot(isnew);
-        const int n = __popcll(newmask);
-        stage_ids[isnew ? __popcll(newmask & ((1ull << lane) - 1ull)) : WAVE] = id;  // keeps link order; slot 64 = bin
-        vis_count += n;
-        wave_sync();
-        PH_MARK(4);
-        if (n == 0) continue;
-        n_dist += n;
+      }
+      ovf = __ballot(ovf) != 0ull;  // wave-uniform
+      const unsigned long long newmask = __ballot(isnew);
+      const int n = __popcll(newmask);
+      stage_ids[isnew ? __popcll(newmask & ((1ull << lane) - 1ull)) : WAVE] = id;  // keeps link order; slot 64 = bin
+      vis_count += n;
+      wave_sync();
+      PH_MARK(4);
+      if (n == 0) continue;
+      n_dist += n;
 
-        constexpr int VPW = WAVE / G;
-        const int v = lane / G;
-        const bool group_leader = (lane % G) == 0;
-        for (int base = 0; base < n; base += VPW * PU) {
-          // ---- distances of this batch, kept in registers: slot = base + pu*VPW + v lives in lane v*G
-          uint32_t cid[PU];
-          bool cval[PU];
-          float cd[PU];
+      constexpr int VPW = WAVE / G;
+      const int v = lane / G;
+      const bool group_leader = (lane % G) == 0;
+      for (int base = 0; base < n; base += VPW * PU) {
+        // ---- distances of this batch, kept in registers: slot = base + pu*VPW + v lives in lane v*G
+        uint32_t cid[PU];
+        bool cval[PU];
+        float cd[PU];
 #pragma unroll
-          for (int pu = 0; pu < PU; pu++) {
-            const int slot = base + pu * VPW + v;
-            cval[pu] = slot < n;
-            cid[pu] = stage_ids[min(slot, n - 1)];  // lanes past the end re-read the last real id
-          }
-          const int npass = min(PU, (n - base + VPW - 1) / VPW);
-          batch_dists<T, METRIC, G, CU, FULL>(p.vectors, p.row_bytes, (int)p.nchunks, qlds, cid, npass, cd, lane);
-          PH_MARK(5);
+        for (int pu = 0; pu < PU; pu++) {
+          const int slot = base + pu * VPW + v;
+          cval[pu] = slot < n;
+          cid[pu] = stage_ids[min(slot, n - 1)];  // lanes past the end re-read the last real id
+        }
+        const int npass = min(PU, (n - base + VPW - 1) / VPW);
+        batch_dists<T, METRIC, G, CU, FULL>(vectors, row_bytes, nchunks, qlds, cid, npass, cd, lane);
+        PH_MARK(5);
 
-          // ---- admissions in link order (Index.h:667-705).  Superset filter first: max_dist never grows
-          // once the beam is full, so whatever fails here would also fail the sequential test.
+        // ---- admissions in link order (Index.h:667-705).  Superset filter first: max_dist never grows
+        // once the beam is full, so whatever fails here would also fail the sequential test.
 #pragma unroll
-          for (int pu = 0; pu < PU; pu++) {
-            if (pu >= npass) break;
-            unsigned long long pm = __ballot(group_leader && cval[pu] && (nbr_n < B || cd[pu] < max_dist));
-            while (pm) {
-              const int i = __ffsll((long long)pm) - 1;
-              pm &= pm - 1;
-              const float di = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cd[pu]), i));
-              const uint32_t idi = (uint32_t)__builtin_amdgcn_readlane((int)cid[pu], i);
-              if (nbr_n < B || di < max_dist) {  // Index.h:693
-                if (cand_n >= (int)(p.cand_slots + p.spill_entries)) {
+        for (int pu = 0; pu < PU; pu++) {
+          if (pu >= npass) break;
+          unsigned long long pm = __ballot(group_leader && cval[pu] && (nbr_n < B || cd[pu] < max_dist));
+          while (pm) {
+            const int i = __ffsll((long long)pm) - 1;
+            pm &= pm - 1;
+            const float di = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cd[pu]), i));
+            const uint32_t idi = (uint32_t)__builtin_amdgcn_readlane((int)cid[pu], i);
+            if (nbr_n < B || di < max_dist) {  // Index.h:693
+              if (cand_n < cand_slots) {
+                coop_push(cand, cand_n, fnv_stl::Entry{-di, idi}, lane, ph, 11);
+              } else {
+                const int spill_entries = (int)cold_args()->spill_entries;
+                if (cand_n >= cand_slots + spill_entries) {
                   err = ST_CAND_OVERFLOW;
                   pm = 0;
                   break;
                 }
-                if (cand_n < (int)p.cand_slots) {
-                  coop_push(cand, cand_n, fnv_stl::Entry{-di, idi}, lane, ph, 11);
-                } else {
-                  __threadfence_block();
-                  coop_push(cand_big, cand_n, fnv_stl::Entry{-di, idi}, lane, ph, 11);
-                  __threadfence_block();
-                }
-                coop_push(nbr, nbr_n, fnv_stl::Entry{di, idi}, lane, ph, 12);
-                if (nbr_n + 1 > B) coop_pop<false>(nbr, nbr_n + 1, lane, ph, 13);
-                cand_n++;
-                if (nbr_n < B) nbr_n++;
-                max_dist = rfl(nbr.get(0).key);
+                CandHeap cand_big{cand.p, spill, cand_slots};
+                __threadfence_block();
+                coop_push(cand_big, cand_n, fnv_stl::Entry{-di, idi}, lane, ph, 11);
+                __threadfence_block();
               }
+              coop_push(nbr, nbr_n, fnv_stl::Entry{di, idi}, lane, ph, 12);
+              if (nbr_n + 1 > B) coop_pop<false>(nbr, nbr_n + 1, lane, ph, 13);
+              cand_n++;
+              if (nbr_n < B) nbr_n++;
+              max_dist = rfl(nbr.get(0).key);
             }
-            if (err) break;
           }
-          PH_MARK(6);
           if (err) break;
         }
-        wave_sync();  // stage_ids is rewritten by the next row chunk
+        PH_MARK(6);
         if (err) break;
       }
+      wave_sync();  // stage_ids is rewritten by the next row chunk
       if (err) break;
     }
-    PH_MARK(2);
+    if (err) break;
+  }
+  PH_MARK(2);
 
-    // ---- results (Index.h:393-408): drain, std::sort by distance, truncate to K --------------
-    __syncthreads();
-    const int n = nbr_n;
-    const int cnt = n < K ? n : K;
-    unsigned long long* res = reinterpret_cast<unsigned long long*>(smem + p.off_cand);  // candidates are dead now
-    bool tie = false;
-    for (int e = lane; e < n; e += WAVE) {
-      const fnv_stl::Entry me = nbr.get(e);
-      int rank = 0;
-      bool eq = false;
-      for (int j = 0; j < n; j++) {
-        const float dj = nbr.get(j).key;
-        rank += (dj < me.key || (dj == me.key && j < e)) ? 1 : 0;
-        eq |= (dj == me.key && j != e);
-      }
-      if (rank < K) {
-        res[rank] = pack(me);
-        tie |= eq;  // a tie that reaches into the first K positions: order is the library's
-      }
+  // ---- results (Index.h:393-408): drain, std::sort by distance, truncate to K --------------
+  __syncthreads();
+  const int K = cold_args()->K;
+  const int n = nbr_n;
+  const int cnt = n < K ? n : K;
+  // candidates are dead now: their array takes the result list (LDS when it holds B + 1 entries, else the spill area)
+  const bool res_global = cand_slots < B + 1;
+  unsigned long long* res = res_global ? spill : cand.p;
+  bool tie = false;
+  for (int e = lane; e < n; e += WAVE) {
+    const fnv_stl::Entry me = nbr.get(e);
+    int rank = 0;
+    bool eq = false;
+    for (int j = 0; j < n; j++) {
+      const float dj = nbr.get(j).key;
+      rank += (dj < me.key || (dj == me.key && j < e)) ? 1 : 0;
+      eq |= (dj == me.key && j != e);
     }
-    const bool any_tie = __ballot(tie) != 0ull;
-    __syncthreads();
-    if (any_tie) {
-      // Exact replay of the reference's tail: pop everything (descending), std::sort ascending.
-      for (int m = n; m > 1; m--) coop_pop<true>(nbr, m, lane, ph, 7);  // leaves nbr[] ascending
-      __syncthreads();
-      for (int i = lane; i < n; i += WAVE) res[i] = nbr.p[n - 1 - i];  // pop order = descending
-      __syncthreads();
-      if (lane == 0) {
-        LdsHeap r{res};
-        fnv_stl::sort_by_key(r, n);
-      }
-      __syncthreads();
+    if (rank < K) {
+      res[rank] = pack(me);
+      tie |= eq;  // a tie that reaches into the first K positions: order is the library's
     }
+  }
+  const bool any_tie = __ballot(tie) != 0ull;
+  if (res_global) __threadfence_block();
+  __syncthreads();
+  if (any_tie) {
+    // Exact replay of the reference's tail: pop everything (descending), std::sort ascending.
+    for (int m = n; m > 1; m--) coop_pop<true>(nbr, m, lane, ph, 7);  // leaves nbr[] ascending
+    __syncthreads();
+    for (int i = lane; i < n; i += WAVE) res[i] = nbr.p[n - 1 - i];  // pop order = descending
+    if (res_global) __threadfence_block();
+    __syncthreads();
+    if (lane == 0) {
+      LdsHeap r{res};
+      // introsort's explicit stack lives in the (now dead) visited table: >= 512 bytes = 42 frames, the
+      // library's depth limit 2*lg(n) needs at most 25 for beams that fit in LDS
+      fnv_stl::sort_by_key(r, n, reinterpret_cast<int*>(vis), (int)min(64u, cold_args()->vis_bytes / 12u));
+    }
+    if (res_global) __threadfence_block();
+    __syncthreads();
+  }
+  {
+    ColdArgs c = cold_args();
+    const int32_t* labels = c->labels;  // null: construction wants node ids
+    float* od_base = c->out_dist + (uint64_t)qi * K;
+    int32_t* ol_base = c->out_labels + (uint64_t)qi * K;
     for (int k = lane; k < K; k += WAVE) {
       float od = std::numeric_limits<float>::infinity();
       int32_t ol = -1;
       if (k < cnt && !err) {
         fnv_stl::Entry e = unpack(res[k]);
         od = e.key;
-        ol = p.labels ? p.labels[e.val] : (int32_t)e.val;  // null: construction wants node ids
+        ol = labels ? labels[e.val] : (int32_t)e.val;
       }
-      p.out_dist[(uint64_t)qi * K + k] = od;
-      p.out_labels[(uint64_t)qi * K + k] = ol;
+      od_base[k] = od;
+      ol_base[k] = ol;
     }
     if (lane == 0) {
-      if (p.out_count) p.out_count[qi] = err ? 0 : cnt;
-      if (p.out_ndist) p.out_ndist[qi] = n_dist;
-      if (p.out_nhops) p.out_nhops[qi] = n_hops;
-      if (err) atomicMax(p.status, err);
+      if (c->out_count) c->out_count[qi] = err ? 0 : cnt;
+      if (c->out_ndist) c->out_ndist[qi] = n_dist;
+      if (c->out_nhops) c->out_nhops[qi] = n_hops;
+      if (err) atomicMax(c->status, err);
     }
-    PH_MARK(7);
-    PH_FLUSH;
-    if (ovf) {  // give the spill bitmap back zeroed
-      __threadfence();
-      const uint32_t listed = ovf_list[0];
-      if (p.vis_tag16 && listed <= OVF_LIST + p.ovf_cap) {  // every id is on record: clear just their words
-        if ((uint32_t)lane < min(listed, OVF_LIST)) bitmap[ovf_list[1 + lane] >> 5] = 0u;
-        for (uint32_t i = OVF_LIST + lane; i < listed; i += WAVE) bitmap[ovf_glist[i - OVF_LIST] >> 5] = 0u;
-      } else {
-        uint4* b4 = reinterpret_cast<uint4*>(bitmap);
-        for (uint32_t i = lane; i < p.bitmap_words / 4; i += WAVE) b4[i] = make_uint4(0u, 0u, 0u, 0u);
-      }
-      __threadfence();
-    }
-    __syncthreads();
   }
+  PH_MARK(7);
+  if (ovf) clear_spill_bitmap(bitmap, ovf_list, ovf_glist, tagged, lane);
+  __syncthreads();
 }
 
-#if defined(FNV_PHASE_TIMING) || defined(FNV_MICROBENCH)
-// Developer micro-benchmark (profiling builds only): cycles per cooperative heap operation on an
-// LDS heap of `size` entries, `blocks` single-wave workgroups running concurrently.
-__global__ __launch_bounds__(WAVE) void heap_microbench_kernel(int size, int iters, unsigned long long* out) {
+template <typename T, int METRIC, int G, int CU, bool FULL>
+__global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kernel(const SearchParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
-  LdsHeap h{reinterpret_cast<unsigned long long*>(smem + 8)};
-  PhaseTimer ph;
-  ph.start();
-  uint32_t rng = 12345u + blockIdx.x;
-  int n = 0;
-  for (int i = 0; i < size; i++) {
-    rng = rng * 1664525u + 1013904223u;
-    coop_push(h, n, fnv_stl::Entry{(float)(rng >> 8), (uint32_t)i}, lane, ph, 15);
-    n++;
-  }
-  __syncthreads();
-  unsigned long long t0 = clock64();
-  for (int it = 0; it < iters; it++) {
-    rng = rng * 1664525u + 1013904223u;
-    coop_push(h, n, fnv_stl::Entry{(float)(rng >> 8), (uint32_t)it}, lane, ph, 15);
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  unsigned long long t1 = clock64();
-  for (int it = 0; it < iters; it++) {
-    coop_pop<true>(h, n + 1, lane, ph, 12);
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  unsigned long long t2 = clock64();
-  // plain dependent LDS round trips for reference
-  int idx = lane;
-  for (int it = 0; it < iters; it++) idx = (int)(h.p[idx & 63] & 63);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  unsigned long long t3 = clock64();
-  if (lane == 0 && blockIdx.x == 0) {
-    out[0] = (t1 - t0) / iters;
-    out[1] = (t2 - t1) / iters;
-    out[2] = (t3 - t2) / iters;
-    out[3] = (unsigned long long)idx;
-  }
-}
-#endif
+  // hot parameters (scalar registers for the whole launch); everything else is re-read where it is used
+  ExactCtx x;
+  x.vectors = p.vectors;
+  x.links = p.links;
+  x.row_bytes = p.row_bytes;
+  x.nchunks = (int)p.nchunks;
+  x.B = p.B;
+  x.M = (int)p.M;
+  x.cand_slots = (int)p.cand_slots;
+  x.tagged = p.vis_tag16 != 0u;
+  x.vg = VisGeom{p.vis_nmask, p.vis_rshift, p.vis_rmask, p.vis_mult, p.vis_w};
+  x.qlds = reinterpret_cast<uint4*>(smem + p.off_q);
+  x.nbr = reinterpret_cast<unsigned long long*>(smem + p.off_nbr);
+  x.cand = reinterpret_cast<unsigned long long*>(smem + p.off_cand);
+  x.vis = reinterpret_cast<uint32_t*>(smem + p.off_vis);
+  x.stage_ids = reinterpret_cast<uint32_t*>(smem + p.off_stage_ids);
+  x.ovf_list = reinterpret_cast<uint32_t*>(smem + p.off_ovf);
 
-// ---------------------------------------------------------------------------------------------
-// U1: AoS -> SoA re-layout of a staged block of nodes.  One thread per (node, 4-byte word) when
-// everything is word aligned, else per byte.  Links: ids >= n_nodes are flagged; duplicates inside
-// a row are replaced by the node's own id (== already visited, see header comment).
-// ---------------------------------------------------------------------------------------------
-__global__ void relayout_vectors_kernel(const uint8_t* __restrict__ aos, uint64_t node_size, uint64_t data_size,
-                                        uint32_t row_bytes, uint64_t first_node, uint64_t count,
-                                        uint8_t* __restrict__ vectors, int word_ok) {
-  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (word_ok) {
-    const uint32_t wpr = row_bytes / 4;
-    const uint64_t node = tid / wpr;
-    const uint32_t w = (uint32_t)(tid % wpr);
-    if (node >= count) return;
-    uint32_t val = 0;
-    if ((uint64_t)w * 4 < data_size) val = *reinterpret_cast<const uint32_t*>(aos + node * node_size + (uint64_t)w * 4);
-    *reinterpret_cast<uint32_t*>(vectors + (first_node + node) * row_bytes + (uint64_t)w * 4) = val;
-  } else {
-    const uint64_t node = tid / row_bytes;
-    const uint32_t b = (uint32_t)(tid % row_bytes);
-    if (node >= count) return;
-    vectors[(first_node + node) * row_bytes + b] = b < data_size ? aos[node * node_size + b] : (uint8_t)0;
-  }
-}
-
-__global__ void relayout_links_kernel(const uint8_t* __restrict__ aos, uint64_t node_size, uint64_t data_size,
-                                      uint32_t M, uint64_t first_node, uint64_t count, uint64_t n_nodes,
-                                      uint32_t* __restrict__ links, int32_t* __restrict__ labels, int* bad_flag) {
-  const uint64_t node = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (node >= count) return;
-  const uint8_t* base = aos + node * node_size + data_size;
-  const uint32_t self = (uint32_t)(first_node + node);
-  uint32_t* out = links + (first_node + node) * M;
-  for (uint32_t i = 0; i < M; i++) {
-    uint32_t id;
-    memcpy(&id, base + (uint64_t)i * 4, 4);
-    if ((uint64_t)id >= n_nodes) {
-      atomicExch(bad_flag, 1);
-      id = self;
-    }
-    for (uint32_t j = 0; j < i; j++) {
-      uint32_t prev;
-      memcpy(&prev, base + (uint64_t)j * 4, 4);
-      if (prev == id) {
-        id = self;
-        break;
-      }
-    }
-    out[i] = id;
-  }
-  int32_t lab;
-  memcpy(&lab, base + (uint64_t)M * 4, 4);
-  labels[first_node + node] = lab;
-}
-
-// Incremental construction: overwrite the link rows of `count` scattered nodes (same normalisation as above).
-__global__ void scatter_links_kernel(const uint32_t* __restrict__ node_ids, const uint32_t* __restrict__ rows,
-                                     uint64_t count, uint32_t M, uint64_t id_limit, uint32_t* __restrict__ links,
-                                     int* bad_flag) {
-  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= count) return;
-  const uint32_t self = node_ids[r];
-  if ((uint64_t)self >= id_limit) {
-    atomicExch(bad_flag, 1);
-    return;
-  }
-  const uint32_t* in = rows + r * M;
-  uint32_t* out = links + (uint64_t)self * M;
-  for (uint32_t i = 0; i < M; i++) {
-    uint32_t id = in[i];
-    if ((uint64_t)id >= id_limit) {
-      atomicExch(bad_flag, 1);
-      id = self;
-    }
-    for (uint32_t j = 0; j < i; j++)
-      if (in[j] == id) {
-        id = self;
-        break;
-      }
-    out[i] = id;
+  while (true) {
+    const int qi = next_query(lane);
+    if (qi < 0) break;
+    PH_DECL
+    stage_query<T>(x.qlds, x.vis, x.ovf_list, qi, x.tagged, lane);
+    __syncthreads();
+    PH_MARK(0);
+    // ---- entry-point selection (Index.h:845-870): argmin over nodes 0, s, 2s, ... -----------
+    float best_d;
+    const uint32_t entry = entry_point<T, METRIC, G, CU, FULL>(x.vectors, x.row_bytes, x.nchunks, x.qlds, qi, lane, best_d);
+    PH_MARK(1);
+    exact_query<T, METRIC, G, CU, FULL>(x, qi, entry, best_d, lane, ph);
+    PH_FLUSH;
   }
 }
 

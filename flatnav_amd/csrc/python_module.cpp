@@ -60,7 +60,7 @@ class PyIndex : public std::enable_shared_from_this<PyIndex<dist_t, kType>> {
   // add(data, ef_construction, num_initializations=100, labels=None)   [bindings.cpp:64-119, 326-335]
   // device=True (extension): the insertions' beam searches run on the GPU in batches (Index::addBatchDevice).
   void add(const py::array& data_any, int ef_construction, int num_initializations, py::object labels, bool device,
-           uint32_t device_max_batch, bool device_wiring) {
+           uint32_t device_max_batch, bool device_wiring, uint32_t device_bootstrap) {
     dense_array<element_t> data = data_any.cast<dense_array<element_t>>();
     if (data.ndim() != 2 || data.shape(1) != _dim)
       throw std::invalid_argument("Data has incorrect dimensions. data.ndim() = `" + std::to_string(data.ndim()) +
@@ -83,6 +83,7 @@ class PyIndex : public std::enable_shared_from_this<PyIndex<dist_t, kType>> {
     if (device) {
       typename index_t::DeviceBuildOptions opt;
       if (device_max_batch) opt.max_batch = device_max_batch;
+      if (device_bootstrap) opt.bootstrap = device_bootstrap;
       opt.wire_on_device = device_wiring;
       _index->template addBatchDevice<element_t>(raw, ids, ef_construction, num_initializations, opt);
     } else {
@@ -187,9 +188,12 @@ void bindIndex(py::module_& m, const char* name) {
   py::class_<T, std::shared_ptr<T>>(m, name)
       .def("add", &T::add, py::arg("data"), py::arg("ef_construction"), py::arg("num_initializations") = 100,
            py::arg("labels") = py::none(), py::kw_only(), py::arg("device") = false, py::arg("device_max_batch") = 0,
-           py::arg("device_wiring") = true,
-           "Insert vectors (rows of `data`, cast to the index data type) into the graph.  device=True: the "
-           "insertions' beam searches run on the GPU in batches (same graph family, not the same bytes).")
+           py::arg("device_wiring") = true, py::arg("device_bootstrap") = 0,
+           "Insert vectors (rows of `data`, cast to the index data type) into the graph.  device=True: the insertions "
+           "run on the GPU in batches (deterministic; same graph family as the host builder; device_max_batch=1 "
+           "inserts one node at a time and reproduces the single-threaded host / reference graph byte for byte on "
+           "data whose distances are exact).  device_bootstrap: nodes inserted on the host before the first batch "
+           "(default 2048).")
       .def("allocate_nodes", &T::allocateNodes, py::arg("data"),
            "Store vectors without creating edges (follow with build_graph_links).")
       .def("search_single", &T::searchSingle, py::arg("query"), py::arg("K"), py::arg("ef_search"),

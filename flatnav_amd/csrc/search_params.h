@@ -22,6 +22,8 @@ constexpr int PU = FNV_PU;  // vector "passes" whose loads are issued back to ba
 #endif
 
 enum : int { ST_OK = 0, ST_CAND_OVERFLOW = 1 };
+constexpr int SCAN_WAVES = 4;  // entry_scan_kernel (K0): waves per workgroup ...
+constexpr int SCAN_QPB = 32;   // ... and queries per workgroup
 constexpr uint32_t OVF_LIST = 30;  // ids remembered for a cheap clean-up of the HBM visited bitmap
 
 struct SearchParams {
@@ -34,10 +36,9 @@ struct SearchParams {
   int32_t* out_count;       // [nq] or null
   uint64_t* out_ndist;      // [nq] or null
   uint64_t* out_nhops;      // [nq] or null
-  uint32_t* dispenser;      // next query id (exact replay of a redo list: next list position)
-  uint32_t* redo_list;      // fast kernel: queries it abandoned (equal keys at a decision); exact kernel: non-null =
-                            // run exactly these
-  uint32_t* redo_count;
+  uint32_t* dispenser;      // next query id
+  uint32_t* redo_count;     // sorted-beam kernel: [0] queries it searched again exactly (equal keys at a decision),
+                            // [1..4] by reason
   int32_t* status;          // sticky error flag for the whole launch
   uint32_t* ovf_bitmap;     // [nslots][bitmap_words] visited-set spill (all zero between queries)
   uint32_t* ovf_glist;      // [nslots][ovf_cap] ids sent to the bitmap beyond the first OVF_LIST (big indexes only)
@@ -55,13 +56,34 @@ struct SearchParams {
   uint32_t vis_slots, vis_shift, vis_limit;
   uint32_t vis_tag16;      // 1: bucketed tag table (below; tag width vis_w), 0: 32-bit open addressing
   uint32_t vis_w;          // 16: four tags per 8-byte bucket; 21 / 32: three / two tags per 64-bit bucket
-  unsigned long long vis_H, vis_Lo, vis_R;  // vis_w > 16: field MSBs, the other field bits, field replication multiplier
   uint32_t vis_bytes;      // LDS bytes of the table
   uint32_t vis_nmask, vis_rshift, vis_rmask;  // tag16: 2^nbits-1, t = nbits-k, 2^t-1
   uint32_t vis_mult;       // tag16: buckets = vis_mult * 2^k with vis_mult in {1, 3}
   uint32_t off_ovf;        // LDS: [0] count, [1..OVF_LIST] ids that went to the HBM bitmap
   uint32_t cand_slots, spill_entries, bitmap_words, ovf_cap;
   uint32_t off_q, off_nbr, off_cand, off_vis, off_stage_ids;
+};
+
+// Broadcast of lane 0's value into a scalar register ("this value is wave-uniform").
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float rfl(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+// Register discipline.  The parameter block is ~330 bytes = 80+ scalar registers if every field stays live, and the
+// search kernels are persistent (one loop over many queries), so the compiler would keep them all live and spill.
+// Fields that are needed once per query or in rare branches are therefore NOT read from the by-value copy but
+// re-loaded from the kernel-argument segment at the point of use (scalar loads that hit the scalar cache);
+// the empty asm makes the pointer opaque so that the loads are not hoisted back to the kernel entry.
+// The block must be the kernel's first (and only) argument.
+typedef const __attribute__((address_space(4))) SearchParams* ColdArgs;
+__device__ __forceinline__ ColdArgs cold_args() {
+  ColdArgs k = (ColdArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(k));
+  return k;
+}
+
+// The fields of the visited-table geometry that the per-hop probe needs (kept in scalar registers).
+struct VisGeom {
+  uint32_t nmask, rshift, rmask, mult, w;
 };
 
 }  // namespace fnv_dev

@@ -47,24 +47,26 @@ __device__ __forceinline__ int zero_halves(uint32_t w) { return ((w & 0xFFFFu) =
 
 // Bucket geometry: buckets = mult * 2^k (mult 1 or 3, so tables of 2^j or 3*2^j slots exist), t = nbits - k.
 // x = h * mult; bucket = x >> t; the low t bits of x, divided by mult, number the ids inside the bucket.
-__device__ __forceinline__ void tag16_slot(const SearchParams& p, uint32_t h, uint32_t which, uint32_t& bucket,
+__device__ __forceinline__ void tag16_slot(const VisGeom& g, uint32_t h, uint32_t which, uint32_t& bucket,
                                            uint32_t& tag) {
-  const uint32_t x = h * p.vis_mult;
-  bucket = x >> p.vis_rshift;
-  uint32_t rem = x & p.vis_rmask;
-  if (p.vis_mult == 3) rem = (rem * 43691u) >> 17;  // rem / 3, exact below 2^16
+  const uint32_t x = h * g.mult;
+  bucket = x >> g.rshift;
+  uint32_t rem = x & g.rmask;
+  if (g.mult == 3) rem = (rem * 43691u) >> 17;  // rem / 3, exact below 2^16
   tag = (rem << 1) + 1u + which;
 }
 
 // Called by ALL lanes (inactive ones pass act = false).  The probe is straight-line arithmetic (bitwise, no
 // short-circuit branches) inside a wave-uniform retry loop that normally runs once, so EXEC is only touched
 // around the CAS itself -- the scalar unit that manipulates EXEC is shared by every wave of the CU.
-__device__ __forceinline__ bool visited_insert_tag16(uint32_t* tab, const SearchParams& p, bool act, uint32_t id,
+// bitmap / ovf_glist are this slot's HBM spill areas; they are only touched on the rare both-buckets-full path,
+// where the list capacity is re-read from the kernel arguments (cold_args).
+__device__ __forceinline__ bool visited_insert_tag16(uint32_t* tab, const VisGeom& g, bool act, uint32_t id,
                                                      uint32_t* bitmap, uint32_t* ovf_list, uint32_t* ovf_glist,
                                                      bool& used_bitmap) {
   uint32_t b1, b2, t1, t2;
-  tag16_slot(p, (id * 0x9E3779B1u) & p.vis_nmask, 0u, b1, t1);
-  tag16_slot(p, (id * 0x85EBCA6Bu) & p.vis_nmask, 1u, b2, t2);
+  tag16_slot(g, (id * 0x9E3779B1u) & g.nmask, 0u, b1, t1);
+  tag16_slot(g, (id * 0x85EBCA6Bu) & g.nmask, 1u, b2, t2);
   const uint32_t t1x = t1 | (t1 << 16), t2x = t2 | (t2 << 16);  // the tag in both halves of a word
   uint32_t pending = act ? 1u : 0u, isnew = 0u;
   while (__ballot(pending != 0u) != 0ull) {
@@ -103,7 +105,7 @@ __device__ __forceinline__ bool visited_insert_tag16(uint32_t* tab, const Search
           // 4-byte clears while the bitmap is small (125 KB at 1M nodes); for big indexes (ovf_cap > 0: bitmap
           // > 512 KB) a longer list in HBM keeps the clean-up proportional to the ids, not to N
           if (pos < OVF_LIST) ovf_list[1 + pos] = id;
-          else if (pos - OVF_LIST < p.ovf_cap) ovf_glist[pos - OVF_LIST] = id;
+          else if (pos - OVF_LIST < cold_args()->ovf_cap) ovf_glist[pos - OVF_LIST] = id;
           isnew = 1u;
         }
       }
@@ -116,15 +118,17 @@ __device__ __forceinline__ bool visited_insert_tag16(uint32_t* tab, const Search
 // The same scheme with 64-bit buckets of three 21-bit or two 32-bit tags, for id ranges whose remainder does not fit
 // 16 bits at an affordable bucket count (N > 2^24 at 4096 slots): tag width w needs nbits - k <= w - 2.
 // zero-field test, exact per field: Z(x) = ~(((x & Lo) + Lo) | x) & H  (H = field MSBs, Lo = the other field bits).
-__device__ __forceinline__ bool visited_insert_tagw(unsigned long long* tab, const SearchParams& p, bool act, uint32_t id,
+__device__ __forceinline__ bool visited_insert_tagw(unsigned long long* tab, const VisGeom& g, bool act, uint32_t id,
                                                     uint32_t* bitmap, uint32_t* ovf_list, uint32_t* ovf_glist,
                                                     bool& used_bitmap) {
-  const uint32_t h1 = (id * 0x9E3779B1u) & p.vis_nmask, h2 = (id * 0x85EBCA6Bu) & p.vis_nmask;
-  const uint32_t b1 = h1 >> p.vis_rshift, b2 = h2 >> p.vis_rshift;
-  const unsigned long long t1 = ((unsigned long long)(h1 & p.vis_rmask) << 1) + 1ull;
-  const unsigned long long t2 = ((unsigned long long)(h2 & p.vis_rmask) << 1) + 2ull;
-  const unsigned long long H = p.vis_H, Lo = p.vis_Lo;
-  const unsigned long long t1x = t1 * p.vis_R, t2x = t2 * p.vis_R;  // the tag in every field
+  const uint32_t h1 = (id * 0x9E3779B1u) & g.nmask, h2 = (id * 0x85EBCA6Bu) & g.nmask;
+  const uint32_t b1 = h1 >> g.rshift, b2 = h2 >> g.rshift;
+  const unsigned long long t1 = ((unsigned long long)(h1 & g.rmask) << 1) + 1ull;
+  const unsigned long long t2 = ((unsigned long long)(h2 & g.rmask) << 1) + 2ull;
+  // field replication multiplier, field MSBs, the other field bits: three 21-bit or two 32-bit fields
+  const unsigned long long R = g.w == 21 ? (1ull | (1ull << 21) | (1ull << 42)) : (1ull | (1ull << 32));
+  const unsigned long long H = R << (g.w - 1), Lo = R * ((1ull << (g.w - 1)) - 1ull);
+  const unsigned long long t1x = t1 * R, t2x = t2 * R;  // the tag in every field
   uint32_t pending = act ? 1u : 0u, isnew = 0u;
   while (__ballot(pending != 0u) != 0ull) {
     const unsigned long long B1 = tab[b1], B2 = tab[b2];
@@ -137,7 +141,7 @@ __device__ __forceinline__ bool visited_insert_tagw(unsigned long long* tab, con
     const uint32_t full = (e1 | e2) == 0 ? 1u : 0u;
     const bool first = e1 >= e2;  // insert into the emptier bucket
     const unsigned long long z = first ? z1 : z2, oldw = first ? B1 : B2, tag = first ? t1 : t2;
-    const int shift = z ? __ffsll((long long)z) - (int)p.vis_w : 0;  // lowest empty field: its MSB is bit shift + w - 1
+    const int shift = z ? __ffsll((long long)z) - (int)g.w : 0;  // lowest empty field: its MSB is bit shift + w - 1
     const unsigned long long neww = oldw | (tag << shift);
     const uint32_t try_cas = pending & (found ^ 1u) & (full ^ 1u);
     unsigned long long got = ~oldw;
@@ -153,7 +157,7 @@ __device__ __forceinline__ bool visited_insert_tagw(unsigned long long* tab, con
         if (!(old & bit)) {
           const uint32_t pos = atomicAdd(&ovf_list[0], 1u);
           if (pos < OVF_LIST) ovf_list[1 + pos] = id;
-          else if (pos - OVF_LIST < p.ovf_cap) ovf_glist[pos - OVF_LIST] = id;
+          else if (pos - OVF_LIST < cold_args()->ovf_cap) ovf_glist[pos - OVF_LIST] = id;
           isnew = 1u;
         }
       }
@@ -162,12 +166,5 @@ __device__ __forceinline__ bool visited_insert_tagw(unsigned long long* tab, con
   }
   return isnew != 0u;
 }
-
-__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ float rfl(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-
-// ---------------------------------------------------------------------------------------------
-// The search kernel.
-// ---------------------------------------------------------------------------------------------
 
 }  // namespace fnv_dev

@@ -99,8 +99,11 @@ def _np_dtype(name: str):
 class DeviceIndex:
     """An index resident in one GPU's HBM (vectors / links / labels in SoA form)."""
 
-    def __init__(self, handle: C.c_void_p):
+    def __init__(self, handle: C.c_void_p, owned: bool = True):
+        """owned=False: a view of a handle that belongs to someone else (e.g. flatnav.index.*.device_handle());
+        close() / garbage collection then leave it alone."""
         self._h = handle
+        self._owned = owned
         info = (C.c_uint64 * 8)()
         check(lib().fnv_index_info(self._h, info))
         self.dtype = ORD_DTYPE[int(info[0])]
@@ -130,7 +133,8 @@ class DeviceIndex:
 
     def close(self) -> None:
         if getattr(self, "_h", None):
-            lib().fnv_index_free(self._h)
+            if getattr(self, "_owned", True):
+                lib().fnv_index_free(self._h)
             self._h = None
 
     def __del__(self):
@@ -222,7 +226,9 @@ class DeviceIndex:
         return dict(zip(["total", "eviction_tie", "selection_tie", "result_tie", "nan_inf"], [int(x) for x in r]))
 
     def launch_geometry(self) -> dict:
-        g = (C.c_uint64 * 6)()
+        g = (C.c_uint64 * 7)()
         check(lib().fnv_last_launch_geometry(self._h, g))
         keys = ["grid_blocks", "block_threads", "lds_bytes", "blocks_per_cu", "visited_slots", "cand_slots"]
-        return {k: int(g[i]) for i, k in enumerate(keys)}
+        out = {k: int(g[i]) for i, k in enumerate(keys)}
+        out["kernel"] = ["two_heaps", "sorted_beam_registers", "sorted_beam_lds"][int(g[6])]
+        return out

@@ -111,6 +111,38 @@ struct NodeGuard {
   ~NodeGuard() { locks.unlock(node); }
 };
 
+// Which link rows the host builder has changed since the device mirror was last brought up to date (one byte
+// per node, set from any thread), so that the next search ships those rows instead of the whole index.
+class DirtyRows {
+  std::unique_ptr<std::atomic<uint8_t>[]> _flags;
+  std::atomic<uint64_t> _count{0};
+  size_t _n = 0;
+
+ public:
+  void reset(size_t n) {
+    _flags.reset(new std::atomic<uint8_t>[n]);
+    for (size_t i = 0; i < n; ++i) _flags[i].store(0, std::memory_order_relaxed);
+    _count.store(0);
+    _n = n;
+  }
+  void mark(uint32_t node) {
+    if (!_flags[node].exchange(1, std::memory_order_relaxed)) _count.fetch_add(1, std::memory_order_relaxed);
+  }
+  uint64_t count() const { return _count.load(); }
+  // ids < limit that are marked, ascending; clears every mark
+  std::vector<uint32_t> drain(size_t limit) {
+    std::vector<uint32_t> ids;
+    if (_count.load() != 0)
+      for (size_t i = 0; i < _n; ++i)
+        if (_flags[i].load(std::memory_order_relaxed)) {
+          _flags[i].store(0, std::memory_order_relaxed);
+          if (i < limit) ids.push_back(static_cast<uint32_t>(i));
+        }
+    _count.store(0);
+    return ids;
+  }
+};
+
 // Per-thread working memory of the host builder.
 struct BuildScratch {
   std::vector<uint32_t> stamp;  // visited epoch per node
@@ -161,8 +193,11 @@ class Index {
   // device mirror
   mutable std::mutex _device_guard;
   mutable fnv_index_t _device_index = nullptr;
-  mutable bool _device_stale = true;
-  mutable size_t _device_capacity = 0;  // rows allocated on the device (== node count unless built there)
+  mutable bool _device_stale = true;       // the mirror misses host-side changes (new nodes and / or dirty link rows)
+  mutable bool _device_rebuild = true;     // ... and they are not tracked: the whole store must be shipped again
+  mutable size_t _device_capacity = 0;     // rows allocated on the device
+  mutable size_t _device_synced_nodes = 0; // nodes [0, this) have their records on the device
+  mutable detail::DirtyRows _dirty_rows;   // link rows of synced nodes that changed since
   int _device_ordinal = 0;
 
   Index() = default;
@@ -180,6 +215,7 @@ class Index {
   void allocateStore() {
     _index_memory.reset(new char[storeBytes()]());  // zero-filled: saved files are deterministic
     _node_locks.reset(_max_node_count);
+    _dirty_rows.reset(_max_node_count);
   }
 
   template <typename Archive>
@@ -293,10 +329,12 @@ class Index {
   void linkNeighbors(detail::KeyHeap& selected, node_id_t new_id, detail::BuildScratch& s) {
     detail::NodeGuard own(_node_locks, new_id);
     node_id_t* new_links = nodeLinks(new_id);
+    _dirty_rows.mark(new_id);
     size_t slot = 0;
     while (!selected.empty()) {
       const node_id_t nb = selected.top().val;
       new_links[slot++] = nb;
+      _dirty_rows.mark(nb);
       {
         detail::NodeGuard theirs(_node_locks, nb);
         node_id_t* nb_links = nodeLinks(nb);
@@ -327,22 +365,57 @@ class Index {
     }
   }
 
-  void markDeviceStale() { _device_stale = true; }
+  void markDeviceStale() { _device_stale = true; }             // appended nodes / dirty rows: tracked
+  void markDeviceRebuild() { _device_stale = _device_rebuild = true; }  // anything else (reorder, graph import)
 
+  // Brings the device mirror up to date.  A mirror that already holds a prefix of the nodes receives only what
+  // changed -- the appended node records (fnv_index_write_nodes) and the link rows the builder touched
+  // (fnv_index_write_links) -- unless that is most of the index anyway; otherwise the store is shipped whole.
   void ensureDevice() const {
     if (_device_index && !_device_stale) return;
-    if (_device_index) {
-      fnv_index_free(_device_index);
-      _device_index = nullptr;
+    Index* self = const_cast<Index*>(this);
+    const int metric = self->deviceMetric();
+    const uint32_t dim = static_cast<uint32_t>(self->_distance->dimension());
+    const bool incremental = _device_index && !_device_rebuild && _device_capacity >= _cur_num_nodes &&
+                             _device_synced_nodes > 0 && _device_synced_nodes <= _cur_num_nodes &&
+                             _dirty_rows.count() <= _cur_num_nodes / 4;
+    if (incremental) {
+      std::vector<node_id_t> ids = _dirty_rows.drain(_device_synced_nodes);
+      if (_cur_num_nodes > _device_synced_nodes)
+        detail::throwOnDeviceError(fnv_index_write_nodes(_device_index, _device_synced_nodes,
+                                                         _cur_num_nodes - _device_synced_nodes,
+                                                         nodeData(static_cast<node_id_t>(_device_synced_nodes)),
+                                                         _node_size_bytes, _data_size_bytes));
+      if (!ids.empty()) {
+        std::vector<node_id_t> rows(ids.size() * _M);
+        for (size_t t = 0; t < ids.size(); ++t) std::memcpy(rows.data() + t * _M, nodeLinks(ids[t]), _M * sizeof(node_id_t));
+        detail::throwOnDeviceError(fnv_index_write_links(_device_index, ids.data(), rows.data(), ids.size()));
+      }
+      detail::throwOnDeviceError(fnv_index_set_live_nodes(_device_index, _cur_num_nodes));
+    } else {
+      if (_device_index) {
+        fnv_index_free(_device_index);
+        _device_index = nullptr;
+      }
+      if (_cur_num_nodes == _max_node_count) {  // complete: exactly as many rows as nodes
+        detail::throwOnDeviceError(fnv_index_upload(_index_memory.get(), _node_size_bytes, _data_size_bytes,
+                                                    static_cast<uint32_t>(_M), _cur_num_nodes,
+                                                    static_cast<int>(_data_type), metric, dim, _device_ordinal,
+                                                    &_device_index));
+        _device_capacity = _cur_num_nodes;
+      } else {  // still growing: room for every node the store can hold, so that later additions are appended
+        detail::throwOnDeviceError(fnv_index_alloc(static_cast<uint32_t>(_M), _max_node_count,
+                                                   static_cast<int>(_data_type), metric, dim, _device_ordinal,
+                                                   &_device_index));
+        _device_capacity = _max_node_count;
+        detail::throwOnDeviceError(fnv_index_write_nodes(_device_index, 0, _cur_num_nodes, _index_memory.get(),
+                                                         _node_size_bytes, _data_size_bytes));
+        detail::throwOnDeviceError(fnv_index_set_live_nodes(_device_index, _cur_num_nodes));
+      }
+      _dirty_rows.drain(0);
     }
-    const int metric = const_cast<Index*>(this)->_distance->metricType() == MetricType::L2 ? FNV_METRIC_L2 : FNV_METRIC_IP;
-    detail::throwOnDeviceError(fnv_index_upload(_index_memory.get(), _node_size_bytes, _data_size_bytes,
-                                                static_cast<uint32_t>(_M), _cur_num_nodes,
-                                                static_cast<int>(_data_type), metric,
-                                                static_cast<uint32_t>(const_cast<Index*>(this)->_distance->dimension()),
-                                                _device_ordinal, &_device_index));
-    _device_capacity = _cur_num_nodes;
-    _device_stale = false;
+    _device_synced_nodes = _cur_num_nodes;
+    _device_stale = _device_rebuild = false;
   }
 
   int deviceMetric() { return _distance->metricType() == MetricType::L2 ? FNV_METRIC_L2 : FNV_METRIC_IP; }
@@ -350,19 +423,9 @@ class Index {
   // Device index with room for every node the store can hold, holding nodes [0, _cur_num_nodes): what the
   // device-assisted builder appends to.
   void ensureDeviceAtCapacity() {
-    if (_device_index && !_device_stale && _device_capacity == _max_node_count) return;
-    if (_device_index) {
-      fnv_index_free(_device_index);
-      _device_index = nullptr;
-    }
-    detail::throwOnDeviceError(fnv_index_alloc(static_cast<uint32_t>(_M), _max_node_count, static_cast<int>(_data_type),
-                                               deviceMetric(), static_cast<uint32_t>(_distance->dimension()),
-                                               _device_ordinal, &_device_index));
-    _device_capacity = _max_node_count;
-    detail::throwOnDeviceError(
-        fnv_index_write_nodes(_device_index, 0, _cur_num_nodes, _index_memory.get(), _node_size_bytes, _data_size_bytes));
-    detail::throwOnDeviceError(fnv_index_set_live_nodes(_device_index, _cur_num_nodes));
-    _device_stale = false;
+    if (_device_index && _device_capacity != _max_node_count) markDeviceRebuild();
+    if (_cur_num_nodes == _max_node_count) return ensureDevice();
+    ensureDevice();  // allocates at full capacity while the store is not full
   }
 
  public:
@@ -388,7 +451,7 @@ class Index {
     std::lock_guard<std::mutex> g(_device_guard);
     if (ordinal != _device_ordinal) {
       _device_ordinal = ordinal;
-      markDeviceStale();
+      markDeviceRebuild();
     }
   }
   int device() const { return _device_ordinal; }
@@ -430,7 +493,7 @@ class Index {
           break;
         }
     }
-    markDeviceStale();
+    markDeviceRebuild();
   }
 
   std::vector<std::vector<uint32_t>> getGraphOutdegreeTable() {
@@ -506,8 +569,8 @@ class Index {
         label_t label = labels[r];
         this->add(rowPtr(r), label, ef_construction, num_initializations);
       };
-      if (_num_threads == 1) for (uint32_t r = 0; r < nb; ++r) insertRow(r);
-      else flatnav::executeInParallel(0, static_cast<uint32_t>(nb), _num_threads, insertRow);
+      // one thread: the device builder is deterministic from here on, so its start should be too
+      for (uint32_t r = 0; r < nb; ++r) insertRow(r);
       row = nb;
     }
     if (row == total) return;
@@ -608,7 +671,10 @@ class Index {
       if (_num_threads == 1) for (uint32_t n = 0; n < _cur_num_nodes; ++n) unpackRow(n);
       else flatnav::executeInParallel(0, static_cast<uint32_t>(_cur_num_nodes), _num_threads, unpackRow);
     }
-    _device_stale = false;  // the device copy was kept in step
+    // the device copy was kept in step
+    _dirty_rows.drain(0);
+    _device_synced_nodes = _cur_num_nodes;
+    _device_stale = _device_rebuild = false;
   }
 
   void add(void* data, label_t& label, int ef_construction, int num_initializations) {
@@ -763,7 +829,7 @@ class Index {
     for (node_id_t n = 0; n < _cur_num_nodes; ++n)
       std::memcpy(fresh.get() + static_cast<uint64_t>(perm[n]) * _node_size_bytes, nodeData(n), _node_size_bytes);
     _index_memory = std::move(fresh);
-    markDeviceStale();
+    markDeviceRebuild();
   }
 };
 

@@ -193,19 +193,21 @@ FNV_HD int lg2_floor(int n) {  // std::__lg
 // left part.  The order in which disjoint sub-ranges are processed does not
 // change the result (each call only touches its own range), but we keep it
 // anyway.
+// `frames`: caller-provided storage for the explicit stack, 3 ints per frame, `cap` frames.  The library's recursion
+// depth is bounded by the depth limit 2*lg(n) (+1 for the frame in flight), so 64 frames cover every int-sized n.
+// The device kernel hands in LDS (a local array would live in scratch memory).
 template <class A>
-FNV_HD void sort_by_key(A& a, int n) {
+FNV_HD void sort_by_key(A& a, int n, int* frames, int cap) {
   if (n <= 0) return;
   const int THRESH = 16;
-  struct Frame {
-    int first, last, depth;
-  };
-  Frame stack[64];
   int sp = 0;
-  stack[sp++] = Frame{0, n, 2 * lg2_floor(n)};
+  frames[0] = 0;
+  frames[1] = n;
+  frames[2] = 2 * lg2_floor(n);
+  sp = 1;
   while (sp > 0) {
-    Frame f = stack[--sp];
-    int first = f.first, last = f.last, depth = f.depth;
+    --sp;
+    int first = frames[3 * sp], last = frames[3 * sp + 1], depth = frames[3 * sp + 2];
     while (last - first > THRESH) {
       if (depth == 0) {
         heapsort_range(a, first, last);
@@ -217,7 +219,12 @@ FNV_HD void sort_by_key(A& a, int n) {
       int cut = unguarded_partition(a, first + 1, last, first);
       // library: recurse(cut, last, depth); last = cut;  -> right part first.
       // Push the LEFT remainder, continue with the right part now.
-      if (sp < 64) stack[sp++] = Frame{first, cut, depth};
+      if (sp < cap) {
+        frames[3 * sp] = first;
+        frames[3 * sp + 1] = cut;
+        frames[3 * sp + 2] = depth;
+        ++sp;
+      }
       first = cut;
     }
   }
@@ -228,6 +235,12 @@ FNV_HD void sort_by_key(A& a, int n) {
   } else {
     insertion_sort(a, 0, n);
   }
+}
+
+template <class A>
+FNV_HD void sort_by_key(A& a, int n) {
+  int frames[3 * 64];
+  sort_by_key(a, n, frames, 64);
 }
 
 }  // namespace fnv_stl

@@ -143,9 +143,18 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *   "spill_entries"   per-slot HBM spill capacity of the candidate heap (default 16384)
  *   "blocks_per_cu"   cap resident query slots per CU (0 = occupancy limit)
  *   "output_node_ids" 1 = out_labels receives node ids, not labels (used by the device-assisted builder)
- *   "register_beam"   beams <= 64 first run in the register-beam kernel (csrc/fast_search.hpp), which hands queries
- *                     with decision-relevant ties to the exact kernel; same results either way.  0 = never, 1 = always,
- *                     2 (default) = for uint8 / int8 indexes only (measured +5-8 % there, -8-14 % on float32 rows)
+ *   "sorted_beam"     the sorted-beam kernel (csrc/sorted_beam.hpp: the beam as one sorted array instead of the
+ *                     reference's two heaps; a query in which equal distances meet at a decision is searched again
+ *                     by the same wavefront with the exact two-heap code, so results are the same either way):
+ *                     0 = never (two-heap kernel only), 1 = always, 2 (default) = adaptive -- used until more than a
+ *                     fifth of a launch's queries needed the exact search (integer-valued data with wide beams),
+ *                     then the two-heap kernel serves that beam width.  Needs capacity < 2^31 nodes.
+ *   "sorted_beam_min" smallest beam width the sorted-beam kernel is used for (default 1)
+ *   "sorted_cand_lds" where the exact re-run of the sorted-beam kernel keeps its candidates heap: 2 (default) = in LDS
+ *                     when that costs neither resident queries nor visited-table slots, else in the slot's HBM spill
+ *                     area; 0 = always HBM, 1 = always LDS (tests)
+ *   "register_beam"   != 0 (default): beams of at most 64 entries keep the sorted array in registers, wider ones in
+ *                     LDS; 0 = always in LDS
  *   "entry_kernel"    1 = entry points of the whole batch come from the LDS-staged entry_scan_kernel (K0);
  *                     0 (default) = every query scans them inside the search kernel.  Same results bit for
  *                     bit; measured equally fast on MI355X (the shared scan rows are L2 hits either way)
@@ -181,15 +190,15 @@ int fnv_search_status(fnv_index_t index);
  * fnv_search_batch[_device] call on this index; synchronises with that launch. */
 int fnv_last_kernel_ms(fnv_index_t index, float* ms);
 
-/* With option "register_beam" beams of at most 64 entries are searched by the register-beam kernel, which hands a
- * query to the exact (libstdc++-replay) kernel when equal distances meet at a decision.  out[5] = queries of
- * the most recent search that were replayed: {total, eviction tie, selection tie, result tie, NaN/inf};
- * synchronises with that launch.  Results do not depend on the split. */
+/* The sorted-beam kernel searches a query again with the exact (libstdc++-replay) two-heap code when equal
+ * distances meet at a decision.  out[5] = queries of the most recent search that were: {total, eviction tie,
+ * selection tie, result tie, NaN/inf}; synchronises with that launch.  Results do not depend on it. */
 int fnv_last_replayed_queries(fnv_index_t index, uint64_t out[5]);
 
-/* Launch geometry of the most recent search: geom[6] = {grid_blocks, block_threads, lds_bytes,
- * blocks_per_cu, visited_slots, cand_slots}. */
-int fnv_last_launch_geometry(fnv_index_t index, uint64_t geom[6]);
+/* Launch geometry of the most recent search: geom[7] = {grid_blocks, block_threads, lds_bytes,
+ * blocks_per_cu, visited_slots, cand_slots (LDS entries of the exact search's candidates heap), kernel: 0 = two-heap
+ * kernel, 1 = sorted beam in registers, 2 = sorted beam in LDS}. */
+int fnv_last_launch_geometry(fnv_index_t index, uint64_t geom[7]);
 
 #ifdef __cplusplus
 }

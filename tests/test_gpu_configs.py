@@ -1,0 +1,133 @@
+"""The BASELINE.json configurations beyond C2 under -m gpu, at sizes the CPU oracle handles in seconds
+(the full sizes run through bench.py --config ...; FNV_FULLSIZE=1 raises the property tests below to them):
+  C3  768-d float inner product on unit vectors (randn as worded, and the recall-qualified low-rank S3), M=32, ef=200
+  C4  100-d unit vectors (GloVe stand-in), ef in {50, 100, 200, 400}: rows that are not a whole number of lane spans
+  C5  128-d randn L2
+Float contract: distances within rtol 1e-5 (atol 1e-6 near zero), >= 99 % of queries with identical id
+lists -- against the oracle and against the oracle driving the reference's own compiled AVX-512 distance kernel."""
+import os
+
+import numpy as np
+import pytest
+
+from flatnav_amd import datasets as ds
+
+pytestmark = pytest.mark.gpu
+FULL = os.environ.get("FNV_FULLSIZE") == "1"
+
+
+@pytest.fixture(scope="module")
+def hipmod():
+    from flatnav_amd import hip
+
+    assert hip.device_count() >= 1, "no MI355X visible"
+    return hip
+
+
+_CACHE = {}
+
+
+def _oracle_index(oracle_mod, metric, X, M, efc):
+    key = (metric, X.shape, M, efc, float(X[0, 0]), float(X[-1, -1]))
+    if key not in _CACHE:
+        ix = oracle_mod.OracleIndex.create(metric, X.shape[1], X.shape[0], M, "float32")
+        ix.add(X, efc, threads=8)  # multi-threaded oracle build: any valid graph will do for SEARCH parity
+        _CACHE[key] = ix
+    return _CACHE[key]
+
+
+def _float_parity(oracle_mod, hipmod, ix, Q, K, ef, kernels=("default", "two_heaps")):
+    dev = hipmod.DeviceIndex.upload(ix.blob(), ix.node_size, ix.data_size, ix.M, ix.cur_nodes, ix.dtype, ix.metric, ix.dim)
+    ix.use_reference_distance(False)
+    od, ol, ost = ix.search(Q, K, ef, threads=8, stats=True)
+    have_ref = ix.use_reference_distance(True)
+    rd, rl = ix.search(Q, K, ef, threads=8) if have_ref else (None, None)
+    ix.use_reference_distance(False)
+    for kern in kernels:
+        dev.set_option("sorted_beam", 0 if kern == "two_heaps" else 2)
+        gd, gl, gst = dev.search(Q, K, ef, stats=True)
+        same = (ol == gl).all(axis=1)
+        assert same.mean() >= 0.99, "%s: ids identical on only %.3f of the queries" % (kern, same.mean())
+        assert np.allclose(od[same], gd[same], rtol=1e-5, atol=1e-6)
+        # same path through the graph <=> same counters
+        assert (ost["n_dist"][same] == gst["n_dist"][same]).mean() >= 0.99
+        assert (np.diff(gd, axis=1) >= 0).all() and (gst["count"] == K).all()
+        if have_ref:
+            same_r = (rl == gl).all(axis=1)
+            assert same_r.mean() >= 0.99
+            assert np.allclose(rd[same_r], gd[same_r], rtol=1e-5, atol=1e-6)
+    return dev
+
+
+@pytest.mark.parametrize("kind", ["randn_unit", "lowrank_unit"])
+def test_c3_shape_768d_float_inner_product_ef200(oracle_mod, hipmod, kind):
+    N, NQ = (12000, 500) if kind == "randn_unit" else (20000, 1000)
+    if kind == "randn_unit":
+        X, Q = ds.randn(N, NQ, 768, seed=768, normalize=True)
+    else:
+        X, Q = ds.lowrank_normalized(N, NQ, dim=768, rank=32, seed=7712)
+    ix = _oracle_index(oracle_mod, "angular", X, 32, 100)
+    dev = _float_parity(oracle_mod, hipmod, ix, Q, 10, 200)
+    dev.set_option("sorted_beam", 2)
+    dev.search(Q, 10, 200)
+    g = dev.launch_geometry()
+    assert g["kernel"] == "sorted_beam_lds"  # what C3 runs on by default
+    if kind == "lowrank_unit":
+        gt = ds.exact_topk_ip(X, Q, 10)
+        _, gl = dev.search(Q, 10, 200)
+        assert ds.recall_at_k(gl, gt) >= 0.95
+
+
+@pytest.mark.parametrize("ef", [50, 100, 200, 400])
+def test_c4_shape_100d_unit_vectors_ef_sweep(oracle_mod, hipmod, ef):
+    X, Q = ds.lowrank_normalized(30000, 1000, dim=100, rank=24, seed=100)
+    ix = _oracle_index(oracle_mod, "angular", X, 32, 100)
+    _float_parity(oracle_mod, hipmod, ix, Q, 10, ef)
+
+
+def test_c5_shape_128d_randn_l2(oracle_mod, hipmod):
+    X, Q = ds.randn(40000, 1000, 128, seed=50)
+    ix = _oracle_index(oracle_mod, "l2", X, 32, 100)
+    _float_parity(oracle_mod, hipmod, ix, Q, 10, 100)
+
+
+@pytest.mark.parametrize("config,n_small,n_full", [("c3-lowrank", 400_000, 10_000_000), ("c5", 2_000_000, 50_000_000)])
+def test_fullsize_properties(oracle_mod, config, n_small, n_full):
+    # Size-independent properties at (FNV_FULLSIZE=1) the configurations' own sizes, index built on the GPU from data
+    # generated on the GPU: sortedness, exact recomputed distances for every returned id, idempotence across
+    # launches, and GPU == oracle on a 100-query sample of the same blob.
+    import torch
+
+    import flatnav_amd as flatnav
+
+    N = n_full if FULL else n_small
+    dim, metric, ef = (768, "angular", 200) if config == "c3-lowrank" else (128, "l2", 100)
+    NQ, K, M = 2000, 10, 32
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7712 if config == "c3-lowrank" else 50)
+    W = torch.randn((32, dim), generator=g, device="cuda") / 32 ** 0.5
+
+    def gen(m):
+        if config == "c5":
+            return torch.randn((m, dim), generator=g, device="cuda")
+        x = torch.randn((m, 32), generator=g, device="cuda") @ W + 0.05 * torch.randn((m, dim), generator=g, device="cuda")
+        return x / x.norm(dim=1, keepdim=True)
+
+    ix = flatnav.index.create(metric, dim, N, M)
+    ix.set_num_threads(min(16, os.cpu_count() or 1))
+    chunk = 1_000_000 if dim > 256 else 5_000_000
+    for first in range(0, N, chunk):
+        ix.add(gen(min(chunk, N - first)).cpu().numpy(), 100, labels=list(range(first, min(N, first + chunk))), device=True)
+    Q = gen(NQ).cpu().numpy()
+    d, l = ix.search(Q, K, ef)
+    assert (np.diff(d, axis=1) >= 0).all() and l.min() >= 0 and l.max() < N
+    d2, l2 = ix.search(Q, K, ef)
+    assert np.array_equal(d, d2) and np.array_equal(l, l2)
+    blob = np.asarray(ix._raw_blob()).reshape(N, ix._node_size_bytes)
+    rows = blob[l.reshape(-1), : dim * 4].copy().view(np.float32).reshape(NQ, K, dim)
+    exact = ((rows - Q[:, None, :]) ** 2).sum(-1) if metric == "l2" else 1.0 - (rows * Q[:, None, :]).sum(-1)
+    assert np.allclose(exact, d, rtol=1e-4, atol=1e-5)
+    o = oracle_mod.OracleIndex.from_blob(metric, "float32", dim, N, N, M, blob.reshape(-1))
+    od, ol = o.search(Q[:100], K, ef, threads=8)
+    same = (ol == l[:100]).all(axis=1)
+    assert same.mean() >= 0.99 and np.allclose(od[same], d[:100][same], rtol=1e-5, atol=1e-6)

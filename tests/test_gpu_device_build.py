@@ -137,3 +137,42 @@ def test_c_abi_incremental_writes_equal_one_upload(oracle_mod):
         inc.write_nodes(N - 1, blob[: 2 * node_size], node_size, data_size)  # past capacity
     with pytest.raises(RuntimeError):
         inc.write_links(np.array([3], dtype=np.uint32), np.full((1, M), N + 5, dtype=np.uint32))  # id out of range
+
+
+@pytest.mark.parametrize("metric,dt", [("l2", "float32"), ("angular", "float32"), ("l2", "uint8"), ("angular", "uint8"),
+                                       ("l2", "int8"), ("angular", "int8")])
+@pytest.mark.parametrize("spread", ["ties_everywhere", "few_ties"])
+def test_sequential_device_insertion_reproduces_the_oracle_graph(flatnav, oracle_mod, metric, dt, spread):
+    # Construction parity pinned (reference Index.h:353-378, 714-834): inserting ONE node per device batch is the
+    # reference's sequential algorithm -- beam search over the nodes present, selectNeighbors to M/2, connectNeighbors
+    # with first-free-slot / re-prune -- so on data whose distances are exact the graph must equal the oracle's
+    # single-threaded build BYTE FOR BYTE, for all six index types, tie-heavy data included.
+    rng = np.random.default_rng(21)
+    N, dim, M, efc = 1200, 16, 8, 40
+    lo, hi = (0, 4) if spread == "ties_everywhere" else (0, 60)
+    if dt == "int8":
+        lo, hi = lo - hi // 2, hi - hi // 2
+    X = rng.integers(lo, hi, (N, dim)).astype(dt)
+    labels = (rng.permutation(N) * 3 + 11).astype(np.int32)
+    o = oracle_mod.OracleIndex.create(metric, dim, N, M, dt)
+    o.add(X, efc, labels=labels)
+    ix = flatnav.index.create(metric, dim, N, M, getattr(flatnav.data_type.DataType, dt))
+    ix.add(X, efc, labels=labels.tolist(), device=True, device_max_batch=1, device_bootstrap=40)
+    assert ix._cur_num_nodes == N
+    want = np.asarray(o.blob())[: N * o.node_size].reshape(N, o.node_size)
+    got = np.asarray(ix._raw_blob())[: N * o.node_size].reshape(N, o.node_size)
+    bad = np.flatnonzero((want != got).any(axis=1))
+    assert bad.size == 0, "first differing node %d of %d differing" % (bad[0], bad.size)
+
+
+def test_batched_device_build_is_deterministic(flatnav):
+    # Same data, same options -> same bytes, run after run (requests are grouped by a stable sort, not by arrival).
+    N, M = 30000, 32
+    X, _ = ds.sift_like(N, 10)
+    blobs = []
+    for _ in range(2):
+        ix = flatnav.index.create("l2", 128, N, M)
+        ix.set_num_threads(4)
+        ix.add(X, 100, device=True, device_max_batch=4096)
+        blobs.append(np.asarray(ix._raw_blob()).copy())
+    assert np.array_equal(blobs[0], blobs[1])

@@ -144,7 +144,12 @@ def test_spill_paths_stay_exact(oracle_mod, hipmod):
     o = ix.search(Q, 10, 100, stats=True)
     dev = _upload(hipmod, ix)
     dev.set_option("visited_slots", 256)  # 16-bit-tag table, 64 buckets: most ids end up in the bitmap
+    dev.set_option("sorted_beam", 1)  # sorted-beam kernel, exact re-run of the queries with ties
     _assert_exact(o, dev.search(Q, 10, 100, stats=True))
+    assert dev.launch_geometry()["kernel"] == "sorted_beam_lds"
+    dev.set_option("sorted_beam", 0)  # from here on the two-heap kernel alone: its spill paths are the subject
+    _assert_exact(o, dev.search(Q, 10, 100, stats=True))
+    assert dev.launch_geometry()["kernel"] == "two_heaps"
     dev.set_option("visited_wide", 1)     # 32-bit open-addressing table, also far too small
     _assert_exact(o, dev.search(Q, 10, 100, stats=True))
     dev.set_option("visited_slots", 0)    # ... and at its default size
@@ -182,39 +187,68 @@ def test_wide_tag_visited_tables_stay_exact(oracle_mod, hipmod, dt):
                 assert slots == 0 or g["visited_slots"] == slots
 
 
-@pytest.mark.parametrize("case", ["u8_ties", "sift_f32", "randn_ip"])
-def test_register_beam_kernel_stays_exact(oracle_mod, hipmod, case):
-    # Optional register-beam kernel (beams <= 64 as one sorted array in registers): queries in which equal keys
-    # meet at a decision are replayed by the exact kernel; everything must come out bit-identical, counters too.
-    rng = np.random.default_rng(11)
-    if case == "u8_ties":  # every query ties: nearly everything is replayed
-        X = rng.integers(0, 4, (8000, 16)).astype(np.uint8); Q = rng.integers(0, 4, (800, 16)).astype(np.uint8)
+@pytest.mark.parametrize("case", ["u8_ties", "sift_f32", "randn_ip", "i8_ip"])
+def test_sorted_beam_kernel_stays_exact(oracle_mod, hipmod, case):
+    # Sorted-beam kernel (default): the beam as one sorted array -- in registers for beams <= 64, else in LDS.  A
+    # query in which equal keys meet at a decision is searched again by the same wave with the exact two-heap code
+    # (candidates heap in LDS or, when LDS is short, in the HBM spill area); ids, distances, counts and the per-query
+    # counters must equal the two-heap kernel's and the oracle's bit for bit.
+    rng = np.random.default_rng(12)
+    if case == "u8_ties":  # every query ties: nearly everything is searched twice
+        X = rng.integers(0, 4, (8000, 16)).astype(np.uint8); Q = rng.integers(0, 4, (600, 16)).astype(np.uint8)
         metric, dt, M = "l2", "uint8", 16
-    elif case == "sift_f32":  # integer-valued floats: a few per cent are replayed
-        X, Q = ds.sift_like(20000, 800); metric, dt, M = "l2", "float32", 32
-    else:  # float data: (almost) nothing is replayed
-        X, Q = ds.randn(20000, 800, 96, seed=4, normalize=True); metric, dt, M = "ip", "float32", 32
+    elif case == "sift_f32":  # integer-valued floats: a few per cent
+        X, Q = ds.sift_like(20000, 600); metric, dt, M = "l2", "float32", 32
+    elif case == "i8_ip":
+        X = rng.integers(-20, 20, (6000, 40)).astype(np.int8); Q = rng.integers(-20, 20, (400, 40)).astype(np.int8)
+        metric, dt, M = "ip", "int8", 16
+    else:  # float data: (almost) never
+        X, Q = ds.randn(20000, 600, 96, seed=4, normalize=True); metric, dt, M = "ip", "float32", 32
     ix = _build(oracle_mod, metric, dt, X, M)
     dev = _upload(hipmod, ix)
-    for K, ef in ((10, 50), (1, 1), (10, 64), (64, 64), (5, 17)):
-        dev.set_option("register_beam", 0)
+    for K, ef in ((10, 100), (10, 65), (10, 64), (1, 1), (5, 17), (64, 64), (100, 100), (10, 128), (10, 129), (10, 200),
+                  (300, 300), (10, 1000)):
+        dev.set_option("sorted_beam", 0)
         want = dev.search(Q, K, ef, stats=True)
-        assert dev.replayed_queries()["total"] == 0
-        dev.set_option("register_beam", 1)
-        got = dev.search(Q, K, ef, stats=True)
-        _assert_exact(want, got)
+        assert dev.replayed_queries()["total"] == 0 and dev.launch_geometry()["kernel"] == "two_heaps"
         if case != "randn_ip":
-            _assert_exact(ix.search(Q, K, ef, stats=True), got)
-        r = dev.replayed_queries()
-        assert r["total"] == r["eviction_tie"] + r["selection_tie"] + r["result_tie"] + r["nan_inf"] <= len(Q)
-        if case == "u8_ties" and ef >= 17:
-            assert r["total"] > len(Q) // 2
-    dev.set_option("visited_slots", 256)  # visited ids overflow into the HBM bitmap in both kernels
-    _assert_exact(want, dev.search(Q, 5, 17, stats=True))
+            _assert_exact(ix.search(Q, K, ef, stats=True), want)
+        dev.set_option("sorted_beam", 1)
+        forms = [(1, "sorted_beam_registers" if max(K, ef) <= 64 else "sorted_beam_lds", 2), (0, "sorted_beam_lds", 2),
+                 (0, "sorted_beam_lds", 0), (1, None, 1)]
+        for regs, kernel, cand_lds in forms:
+            dev.set_option("register_beam", regs)
+            dev.set_option("sorted_cand_lds", cand_lds)  # 0: the exact re-run keeps its candidates heap in HBM
+            got = dev.search(Q, K, ef, stats=True)
+            g = dev.launch_geometry()
+            assert kernel is None or g["kernel"] == kernel
+            assert (g["cand_slots"] == 0) == (cand_lds == 0) or cand_lds == 2
+            _assert_exact(want, got)
+            r = dev.replayed_queries()
+            assert r["total"] == r["eviction_tie"] + r["selection_tie"] + r["result_tie"] + r["nan_inf"] <= len(Q)
+            if case == "u8_ties" and ef >= 17:
+                assert r["total"] > len(Q) // 2
+            if case == "randn_ip" and ef <= 200:
+                assert r["total"] <= len(Q) // 20
+    dev.set_option("sorted_cand_lds", 2)
+    dev.set_option("visited_slots", 256)  # visited ids overflow into the HBM bitmap, in the first pass and the re-run
+    _assert_exact(want, dev.search(Q, 10, 1000, stats=True))
     dev.set_option("visited_slots", 0)
-    dev.set_option("register_beam", 2)  # the default: only 1-byte element types take the register-beam kernel
-    _assert_exact(want, dev.search(Q, 5, 17, stats=True))
-    assert (dev.replayed_queries()["total"] > 0) == (case == "u8_ties")
+    # adaptive default: launches of >= 2048 queries are timed, both kernels get their samples, the faster one stays;
+    # where (almost) every query ties that is the two-heap kernel.  Whatever runs, the bytes are the same.
+    dev.set_option("sorted_beam", 2)
+    Qbig = np.tile(Q, (4, 1))
+    first, kernels = None, []
+    for _ in range(7):
+        got = dev.search(Qbig, 10, 100, stats=True)
+        kernels.append(dev.launch_geometry()["kernel"])
+        dev.replayed_queries()  # synchronises: the launch's timing is complete when the next call looks at it
+        if first is None:
+            first = got
+        _assert_exact(first, got)
+    assert kernels[0] == "sorted_beam_lds" and "two_heaps" in kernels
+    if case == "u8_ties":
+        assert kernels[-1] == "two_heaps"
 
 
 def test_labels_and_duplicate_links(oracle_mod, hipmod):
@@ -268,7 +302,10 @@ def test_large_beams(oracle_mod, hipmod, ef, K):
     X, Q = ds.sift_like(20000, 60)
     ix = _build(oracle_mod, "l2", "float32", X, 32)
     dev = _upload(hipmod, ix)
-    _assert_exact(ix.search(Q, K, ef, stats=True), dev.search(Q, K, ef, stats=True))
+    o = ix.search(Q, K, ef, stats=True)
+    _assert_exact(o, dev.search(Q, K, ef, stats=True))
+    dev.set_option("sorted_beam", 0)  # the two-heap kernel alone (default: sorted beam first, replay on ties)
+    _assert_exact(o, dev.search(Q, K, ef, stats=True))
 
 
 def test_beam_too_large_for_lds_is_an_error(oracle_mod, hipmod):
