@@ -313,6 +313,7 @@ def main() -> None:
                               d_cnt.data_ptr(), d_nd.data_ptr(), d_nh.data_ptr(), stream=stream.cuda_stream)
         for i in range(warmup):
             step(i)
+            torch.cuda.synchronize()  # untimed; lets the library's kernel auto-choice see each warm-up launch's timing
         barrier()
         dev.status()
         evs = []
@@ -383,13 +384,13 @@ def main() -> None:
     sustained = None
     if not args.no_secondary:
         if args.sustain_seconds > 0:
-            sm = measure(EF, max(args.steps, 10), 2, args.sustain_seconds)
+            sm = measure(EF, max(args.steps, 10), 5, args.sustain_seconds)
             sustained = {"steps": sm["steps"], "seconds": sm["elapsed"], "value": sm["qps"], "unit": "queries/s",
                          "ms_per_step": sm["elapsed"] / sm["steps"] * 1e3,
                          "note": ">= %.1f s of back-to-back steps over %d rotating query batches (the contract line "
                                  "above times exactly --steps launches)" % (args.sustain_seconds, nb)}
         for ef2 in cfg["secondary"]:
-            m2 = measure(ef2, max(5, min(args.steps, 20)), 2)
+            m2 = measure(ef2, max(5, min(args.steps, 20)), 5)
             rec2 = recall_at(ef2) if rank == 0 else None
             secondary.append({"ef_search": ef2, "value": m2["qps"], "unit": "queries/s",
                               "recall_at_10": None if rec2 is None else round(rec2, 4),

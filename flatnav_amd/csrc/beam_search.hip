@@ -141,6 +141,20 @@ struct LaunchPlan {
   int bpc = 0, sbpc = 0;
 };
 
+// A host-buffer search that went through the pinned staging buffer: what search_host_finish copies where.
+struct PinnedCall {
+  bool active = false;
+  const uint8_t* slab = nullptr;
+  const int32_t* status = nullptr;
+  uint64_t nq = 0;
+  int K = 0;
+  size_t o_lab = 0, o_cnt = 0, o_nd = 0, o_nh = 0;
+  float* out_dist = nullptr;
+  int32_t* out_labels = nullptr;
+  int32_t* out_count = nullptr;
+  uint64_t *out_ndist = nullptr, *out_nhops = nullptr;
+};
+
 struct fnv_index_s {
   int device = 0;
   int dtype = FNV_DTYPE_FLOAT32, metric = FNV_METRIC_L2;
@@ -185,6 +199,8 @@ struct fnv_index_s {
   unsigned long long* d_spill = nullptr;
   size_t spill_bytes = 0;
   // staging for the host-buffer entry point
+  void* h_pin = nullptr;  // 1 MB of pinned host memory: staging of small host-buffer searches
+  PinnedCall pin;
   void* d_q = nullptr;
   size_t d_q_bytes = 0;
   void* d_out = nullptr;
@@ -292,7 +308,7 @@ int write_nodes_impl(fnv_index_s* ix, uint64_t first_node, uint64_t count_nodes,
 extern "C" {
 
 const char* fnv_last_error(void) { return g_err.c_str(); }
-const char* fnv_version(void) { return "flatnav_hip gfx950 r1"; }
+const char* fnv_version(void) { return "flatnav_hip gfx950 r2"; }
 
 int fnv_device_count(int* count) {
   if (!count) return fail(FNV_ERR_INVALID, "count is null");
@@ -390,6 +406,7 @@ int fnv_index_free(fnv_index_t ix) {
   void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_bitmap, ix->d_ovf, ix->d_nodestage, ix->d_linkstage, ix->d_wirebuf, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase, ix->d_entry};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  if (ix->h_pin) (void)hipHostFree(ix->h_pin);
   if (ix->ev0) (void)hipEventDestroy(ix->ev0);
   if (ix->ev1) (void)hipEventDestroy(ix->ev1);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -645,12 +662,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     p.nchunks = ix->row_bytes / 16;
     p.K = K;
     p.B = B;
-    int cfg = kNumCfgs - 1;
-    for (int c = 0; c < kNumCfgs; c++)
-      if ((uint32_t)(kCfgs[c].G * kCfgs[c].CU) >= p.nchunks) {
-        cfg = c;
-        break;
-      }
+    const int cfg = pick_row_cfg(p.nchunks);
     const uint32_t per_iter = (uint32_t)(kCfgs[cfg].G * kCfgs[cfg].CU);
     p.q_chunks = (p.nchunks + per_iter - 1) / per_iter * per_iter;
     p.cand_slots = ix->cand_slots ? (uint32_t)ix->cand_slots : (uint32_t)(ix->cand_factor * p.B + 192);
@@ -723,7 +735,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
       fnv_index_s::Tuner& t = ix->tuner[B];
       if (t.samples[1] < 2) sorted = true;  // two samples each (the first launch of a kernel is a cold one)
       else if (t.samples[0] < 2) sorted = false;
-      else sorted = t.best[1] <= t.best[0] * 1.02f;
+      else sorted = t.best[1] <= t.best[0];
       sample = t.samples[sorted ? 1 : 0] < 3;
     }
   }
@@ -812,15 +824,12 @@ int fnv_search_status(fnv_index_t ix) {
   return FNV_OK;
 }
 
-int fnv_search_batch(fnv_index_t ix, const void* queries, uint64_t nq, int K, int ef_search, int num_initializations,
-                     float* out_dist, int32_t* out_labels, int32_t* out_count, uint64_t* out_ndist,
-                     uint64_t* out_nhops) {
-  if (!ix) return fail(FNV_ERR_INVALID, "index is null");
-  if (num_initializations <= 0) return fail(FNV_ERR_INVALID, "num_initializations must be greater than 0.");
-  if (K <= 0 || ef_search <= 0) return fail(FNV_ERR_INVALID, "K and ef_search must be positive");
-  if (nq == 0) return FNV_OK;
-  if (!queries || !out_dist || !out_labels) return fail(FNV_ERR_INVALID, "null buffer");
-  std::lock_guard<std::mutex> host_lock(ix->host_mu);  // concurrent callers share one staging area: serialise
+// Host-buffer search in two halves, so that several devices can be kept busy by one caller: enqueue (H2D of the
+// queries, the search launch, D2H of the results -- all asynchronous on the index's own stream; the caller holds
+// ix->host_mu) and finish (wait, report a capacity error).
+static int search_host_enqueue(fnv_index_t ix, const void* queries, uint64_t nq, int K, int ef_search,
+                               int num_initializations, float* out_dist, int32_t* out_labels, int32_t* out_count,
+                               uint64_t* out_ndist, uint64_t* out_nhops) {
   HIP_TRY(hipSetDevice(ix->device));
   const size_t qbytes = (size_t)nq * ix->dim * dtype_size(ix->dtype);
   // one output slab: dist | labels | count | ndist | nhops
@@ -830,36 +839,211 @@ int fnv_search_batch(fnv_index_t ix, const void* queries, uint64_t nq, int K, in
   const size_t o_nd = (o_cnt + (size_t)nq * 4 + 7) & ~(size_t)7;
   const size_t o_nh = o_nd + (size_t)nq * 8;
   const size_t obytes = o_nh + (size_t)nq * 8;
+  // Small batches (a single query above all) go through one pinned host buffer: one H2D copy, one D2H copy of the
+  // whole slab plus the status word, no pageable-memory copies (each of those synchronises) -- the host side of a
+  // one-query search drops from ~10 driver round trips to 4 asynchronous calls and one wait.
+  const size_t qoff = 0, ooff = (qbytes + 63) & ~(size_t)63, soff = ooff + ((obytes + 63) & ~(size_t)63);
+  const bool pinned = soff + 64 <= (1u << 20);
   {
     std::lock_guard<std::mutex> lock(ix->mu);
-    if (qbytes > ix->d_q_bytes) {
-      if (ix->d_q) HIP_TRY(hipFree(ix->d_q));
-      ix->d_q = nullptr;
-      ix->d_q_bytes = 0;
-      HIP_TRY(hipMalloc(&ix->d_q, qbytes));
-      ix->d_q_bytes = qbytes;
-    }
-    if (obytes > ix->d_out_bytes) {
-      if (ix->d_out) HIP_TRY(hipFree(ix->d_out));
-      ix->d_out = nullptr;
-      ix->d_out_bytes = 0;
-      HIP_TRY(hipMalloc(&ix->d_out, obytes));
-      ix->d_out_bytes = obytes;
-    }
+    int rc = grow(&ix->d_q, &ix->d_q_bytes, qbytes);
+    if (!rc) rc = grow(&ix->d_out, &ix->d_out_bytes, obytes);
+    if (rc) return rc;
+    if (pinned && !ix->h_pin) HIP_TRY(hipHostMalloc(&ix->h_pin, 1u << 20, hipHostMallocDefault));
   }
   uint8_t* o = (uint8_t*)ix->d_out;
-  HIP_TRY(hipMemcpyAsync(ix->d_q, queries, qbytes, hipMemcpyHostToDevice, ix->stream));
+  ix->pin = PinnedCall();
+  if (pinned) {
+    uint8_t* h = (uint8_t*)ix->h_pin;
+    memcpy(h + qoff, queries, qbytes);
+    HIP_TRY(hipMemcpyAsync(ix->d_q, h + qoff, qbytes, hipMemcpyHostToDevice, ix->stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(ix->d_q, queries, qbytes, hipMemcpyHostToDevice, ix->stream));
+  }
   int rc = fnv_search_batch_device(ix, ix->d_q, nq, K, ef_search, num_initializations, (float*)(o + o_dist),
                                    (int32_t*)(o + o_lab), (int32_t*)(o + o_cnt), (uint64_t*)(o + o_nd),
                                    (uint64_t*)(o + o_nh), ix->stream);
   if (rc) return rc;
+  if (pinned) {
+    uint8_t* h = (uint8_t*)ix->h_pin;
+    HIP_TRY(hipMemcpyAsync(h + ooff, o, obytes, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipMemcpyAsync(h + soff, ix->d_dispenser + 1, sizeof(int32_t), hipMemcpyDeviceToHost, ix->stream));
+    PinnedCall& c = ix->pin;
+    c.active = true;
+    c.slab = h + ooff;
+    c.status = (const int32_t*)(h + soff);
+    c.nq = nq;
+    c.K = K;
+    c.o_lab = o_lab; c.o_cnt = o_cnt; c.o_nd = o_nd; c.o_nh = o_nh;
+    c.out_dist = out_dist; c.out_labels = out_labels; c.out_count = out_count; c.out_ndist = out_ndist; c.out_nhops = out_nhops;
+    return FNV_OK;
+  }
   HIP_TRY(hipMemcpyAsync(out_dist, o + o_dist, (size_t)nq * K * 4, hipMemcpyDeviceToHost, ix->stream));
   HIP_TRY(hipMemcpyAsync(out_labels, o + o_lab, (size_t)nq * K * 4, hipMemcpyDeviceToHost, ix->stream));
   if (out_count) HIP_TRY(hipMemcpyAsync(out_count, o + o_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, ix->stream));
   if (out_ndist) HIP_TRY(hipMemcpyAsync(out_ndist, o + o_nd, (size_t)nq * 8, hipMemcpyDeviceToHost, ix->stream));
   if (out_nhops) HIP_TRY(hipMemcpyAsync(out_nhops, o + o_nh, (size_t)nq * 8, hipMemcpyDeviceToHost, ix->stream));
+  return FNV_OK;
+}
+
+static int search_host_finish(fnv_index_t ix) {
+  HIP_TRY(hipSetDevice(ix->device));
   HIP_TRY(hipStreamSynchronize(ix->stream));
-  return fnv_search_status(ix);
+  PinnedCall& c = ix->pin;
+  if (!c.active) return fnv_search_status(ix);
+  c.active = false;
+  const size_t nk = (size_t)c.nq * c.K * 4;
+  memcpy(c.out_dist, c.slab, nk);
+  memcpy(c.out_labels, c.slab + c.o_lab, nk);
+  if (c.out_count) memcpy(c.out_count, c.slab + c.o_cnt, (size_t)c.nq * 4);
+  if (c.out_ndist) memcpy(c.out_ndist, c.slab + c.o_nd, (size_t)c.nq * 8);
+  if (c.out_nhops) memcpy(c.out_nhops, c.slab + c.o_nh, (size_t)c.nq * 8);
+  if (*c.status == ST_CAND_OVERFLOW)
+    return fail(FNV_ERR_CAPACITY, "candidate heap overflowed its HBM spill area; raise the spill_entries option");
+  return FNV_OK;
+}
+
+static int check_search_args(fnv_index_t ix, const void* queries, uint64_t nq, int K, int ef_search,
+                             int num_initializations, const float* out_dist, const int32_t* out_labels) {
+  if (!ix) return fail(FNV_ERR_INVALID, "index is null");
+  if (num_initializations <= 0) return fail(FNV_ERR_INVALID, "num_initializations must be greater than 0.");
+  if (K <= 0 || ef_search <= 0) return fail(FNV_ERR_INVALID, "K and ef_search must be positive");
+  if (nq && (!queries || !out_dist || !out_labels)) return fail(FNV_ERR_INVALID, "null buffer");
+  return FNV_OK;
+}
+
+int fnv_search_batch(fnv_index_t ix, const void* queries, uint64_t nq, int K, int ef_search, int num_initializations,
+                     float* out_dist, int32_t* out_labels, int32_t* out_count, uint64_t* out_ndist,
+                     uint64_t* out_nhops) {
+  int rc = check_search_args(ix, queries, nq, K, ef_search, num_initializations, out_dist, out_labels);
+  if (rc || nq == 0) return rc;
+  std::lock_guard<std::mutex> host_lock(ix->host_mu);  // concurrent callers share one staging area: serialise
+  rc = search_host_enqueue(ix, queries, nq, K, ef_search, num_initializations, out_dist, out_labels, out_count,
+                           out_ndist, out_nhops);
+  if (rc) return rc;
+  return search_host_finish(ix);
+}
+
+// ---- several GPUs behind one call -----------------------------------------------------------------
+int fnv_replicate(fnv_index_t src, int n_devices, const int* devices, fnv_index_t* out) {
+  if (!src || !out || n_devices <= 0) return fail(FNV_ERR_INVALID, "null argument");
+  int visible = 0;
+  HIP_TRY(hipGetDeviceCount(&visible));
+  for (int i = 0; i < n_devices; i++) out[i] = nullptr;
+  auto undo = [&]() {
+    for (int i = 0; i < n_devices; i++) {
+      if (out[i]) fnv_index_free(out[i]);
+      out[i] = nullptr;
+    }
+  };
+  for (int i = 0; i < n_devices; i++) {
+    const int dev = devices ? devices[i] : i;
+    if (dev < 0 || dev >= visible) {
+      undo();
+      return fail(FNV_ERR_INVALID, "fnv_replicate: device ordinal " + std::to_string(dev) + " is not visible");
+    }
+    int rc = fnv_index_alloc(src->M, src->capacity, src->dtype, src->metric, src->dim, dev, &out[i]);
+    if (rc) {
+      undo();
+      return rc;
+    }
+  }
+  int rc = fnv_replica_refresh(src, n_devices, out);
+  if (rc) undo();
+  return rc;
+}
+
+int fnv_replica_refresh(fnv_index_t src, int n_replicas, fnv_index_t* replicas) {
+  if (!src || (!replicas && n_replicas)) return fail(FNV_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lock(src->mu);
+  const uint64_t live = src->n_nodes;
+  const size_t bytes[3] = {(size_t)live * src->row_bytes, (size_t)live * src->M * 4, (size_t)live * 4};
+  for (int i = 0; i < n_replicas; i++) {
+    fnv_index_t r = replicas[i];
+    if (!r || r->capacity < live || r->row_bytes != src->row_bytes || r->M != src->M || r->dtype != src->dtype ||
+        r->metric != src->metric)
+      return fail(FNV_ERR_INVALID, "fnv_replica_refresh: replica geometry does not match the source index");
+  }
+  // Doubling tree of peer copies over xGMI: in every round each index that already holds the data feeds one that
+  // does not (1 -> 2 -> 4 -> 8 holders: three rounds for eight GPUs, every link busy once per round).  The copies
+  // of a round run concurrently on the destination indexes' streams.
+  for (int i = 0; i < n_replicas; i++)  // direct xGMI copies where the platform allows them (else staged by the runtime)
+    if (replicas[i]->device != src->device) {
+      (void)hipSetDevice(replicas[i]->device);
+      (void)hipDeviceEnablePeerAccess(src->device, 0);
+      for (int j = 0; j < n_replicas; j++)
+        if (replicas[j]->device != replicas[i]->device) (void)hipDeviceEnablePeerAccess(replicas[j]->device, 0);
+    }
+  (void)hipGetLastError();  // "peer access already enabled" is not an error
+  std::vector<fnv_index_t> have{src}, need(replicas, replicas + n_replicas);
+  size_t next = 0;
+  while (next < need.size()) {
+    const size_t senders = have.size();
+    std::vector<fnv_index_t> round;
+    for (size_t s = 0; s < senders && next < need.size(); s++, next++) {
+      fnv_index_t from = have[s], to = need[next];
+      const void* srcp[3] = {from->d_vectors, from->d_links, from->d_labels};
+      void* dstp[3] = {to->d_vectors, to->d_links, to->d_labels};
+      HIP_TRY(hipSetDevice(to->device));
+      for (int b = 0; b < 3; b++) {
+        if (from->device == to->device)
+          HIP_TRY(hipMemcpyAsync(dstp[b], srcp[b], bytes[b], hipMemcpyDeviceToDevice, to->stream));
+        else
+          HIP_TRY(hipMemcpyPeerAsync(dstp[b], to->device, srcp[b], from->device, bytes[b], to->stream));
+      }
+      round.push_back(to);
+    }
+    for (fnv_index_t to : round) {
+      HIP_TRY(hipSetDevice(to->device));
+      HIP_TRY(hipStreamSynchronize(to->stream));
+      to->n_nodes = live;
+      have.push_back(to);
+    }
+  }
+  HIP_TRY(hipSetDevice(src->device));
+  return FNV_OK;
+}
+
+int fnv_search_batch_multi(fnv_index_t* indexes, int n_indexes, const void* queries, uint64_t nq, int K, int ef_search,
+                           int num_initializations, float* out_dist, int32_t* out_labels, int32_t* out_count,
+                           uint64_t* out_ndist, uint64_t* out_nhops) {
+  if (!indexes || n_indexes <= 0) return fail(FNV_ERR_INVALID, "null argument");
+  int rc = check_search_args(indexes[0], queries, nq, K, ef_search, num_initializations, out_dist, out_labels);
+  if (rc || nq == 0) return rc;
+  for (int g = 1; g < n_indexes; g++)
+    if (!indexes[g] || indexes[g]->dim != indexes[0]->dim || indexes[g]->dtype != indexes[0]->dtype)
+      return fail(FNV_ERR_INVALID, "fnv_search_batch_multi: indexes differ in geometry");
+  // rows [g * ceil(Q/G), ...) go to index g; every device gets its H2D copy, launch and D2H copies
+  // enqueued on its own stream before the first one is waited for
+  const uint64_t per = (nq + (uint64_t)n_indexes - 1) / (uint64_t)n_indexes;
+  const size_t qrow = (size_t)indexes[0]->dim * dtype_size(indexes[0]->dtype);
+  std::vector<std::unique_lock<std::mutex>> locks;
+  int first_error = FNV_OK;
+  std::string first_msg;
+  int enqueued = 0;
+  for (int g = 0; g < n_indexes; g++) {
+    const uint64_t lo = std::min<uint64_t>(nq, (uint64_t)g * per), hi = std::min<uint64_t>(nq, lo + per);
+    if (hi == lo) break;
+    locks.emplace_back(indexes[g]->host_mu);
+    rc = search_host_enqueue(indexes[g], (const uint8_t*)queries + lo * qrow, hi - lo, K, ef_search, num_initializations,
+                             out_dist + lo * K, out_labels + lo * K, out_count ? out_count + lo : nullptr,
+                             out_ndist ? out_ndist + lo : nullptr, out_nhops ? out_nhops + lo : nullptr);
+    enqueued = g + 1;
+    if (rc) {
+      first_error = rc;
+      first_msg = g_err;
+      break;
+    }
+  }
+  for (int g = 0; g < enqueued; g++) {
+    rc = search_host_finish(indexes[g]);
+    if (rc && !first_error) {
+      first_error = rc;
+      first_msg = g_err;
+    }
+  }
+  if (first_error) return fail(first_error, first_msg);
+  return FNV_OK;
 }
 
 int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, int ef_construction,
@@ -888,20 +1072,9 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
   const size_t obytes = o_nd + (size_t)count * 8;
   {
     std::lock_guard<std::mutex> lock(ix->mu);
-    if (qbytes > ix->d_q_bytes) {
-      if (ix->d_q) HIP_TRY(hipFree(ix->d_q));
-      ix->d_q = nullptr;
-      ix->d_q_bytes = 0;
-      HIP_TRY(hipMalloc(&ix->d_q, qbytes));
-      ix->d_q_bytes = qbytes;
-    }
-    if (obytes > ix->d_out_bytes) {
-      if (ix->d_out) HIP_TRY(hipFree(ix->d_out));
-      ix->d_out = nullptr;
-      ix->d_out_bytes = 0;
-      HIP_TRY(hipMalloc(&ix->d_out, obytes));
-      ix->d_out_bytes = obytes;
-    }
+    int rcg = grow(&ix->d_q, &ix->d_q_bytes, qbytes);
+    if (!rcg) rcg = grow(&ix->d_out, &ix->d_out_bytes, obytes);
+    if (rcg) return rcg;
   }
   const size_t nreq = (size_t)count * keep;
   size_t sort_bytes = 0;
@@ -946,12 +1119,7 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
   w.keep = keep;
   w.row_bytes = ix->row_bytes;
   w.nchunks = ix->row_bytes / 16;
-  int cfg = kNumCfgs - 1;
-  for (int c = 0; c < kNumCfgs; c++)
-    if ((uint32_t)(kCfgs[c].G * kCfgs[c].CU) >= w.nchunks) {
-      cfg = c;
-      break;
-    }
+  const int cfg = pick_row_cfg(w.nchunks);
   const uint32_t per_iter = (uint32_t)(kCfgs[cfg].G * kCfgs[cfg].CU);
   w.q_chunks = (w.nchunks + per_iter - 1) / per_iter * per_iter;
   const bool full = (w.nchunks % per_iter) == 0;

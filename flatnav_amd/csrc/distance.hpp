@@ -128,7 +128,8 @@ struct Dist<int8_t, METRIC> : DistInt<int8_t, METRIC> {};
 // entry-scan kernel (same arithmetic and summation order in both, so their distances agree bit for bit).
 template <typename T, int METRIC, int G, int CU, bool FULL>
 __device__ __forceinline__ void batch_dists(const uint8_t* rows, uint32_t row_stride, int nchunks, const uint4* qlds,
-                                            const uint32_t (&id)[PU], int npass, float (&out)[PU], int lane) {
+                                            const uint32_t (&id)[passes<G, CU>()], int npass, float (&out)[passes<G, CU>()], int lane) {
+  constexpr int PU = passes<G, CU>();
   typedef Dist<T, METRIC> D;
   typedef typename D::acc_t acc_t;
   const int g = lane % G;

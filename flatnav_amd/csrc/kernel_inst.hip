@@ -25,7 +25,8 @@ constexpr int METRIC = FNV_INST_METRIC;
   slot[2][FULL] = K<T, METRIC, 8, 4, FULL __VA_ARGS__>;                \
   slot[3][FULL] = K<T, METRIC, 16, 4, FULL __VA_ARGS__>;               \
   slot[4][FULL] = K<T, METRIC, 32, 4, FULL __VA_ARGS__>;               \
-  slot[5][FULL] = K<T, METRIC, 64, 4, FULL __VA_ARGS__>;
+  slot[5][FULL] = K<T, METRIC, 64, 4, FULL __VA_ARGS__>;               \
+  slot[6][FULL] = K<T, METRIC, 64, 3, FULL __VA_ARGS__>;
 
 template <bool FULL>
 static void fill_rows(KernelTable& t) {

@@ -15,6 +15,7 @@ template <typename T, int METRIC, int G, int CU, bool FULL>
 __device__ __forceinline__ void scan_rows(const uint8_t* rows, uint32_t stride_rows, uint32_t id_mul, int nchunks,
                                           const uint4* qlds, uint32_t count, uint32_t j_base, int lane, float& best_d,
                                           uint32_t& best_j) {
+  constexpr int PU = passes<G, CU>();
   constexpr int VPW = WAVE / G;
   const int v = lane / G;
   for (uint32_t j0 = 0; j0 < count; j0 += VPW * PU) {
@@ -197,6 +198,7 @@ struct ExactCtx {
 template <typename T, int METRIC, int G, int CU, bool FULL>
 __device__ __forceinline__ void exact_query(const ExactCtx& x, int qi, uint32_t entry, float best_d, int lane,
                                             PhaseTimer& ph) {
+  constexpr int PU = passes<G, CU>();
   const uint8_t* const vectors = x.vectors;
   const uint32_t* const links = x.links;
   const uint32_t row_bytes = x.row_bytes;

@@ -169,6 +169,8 @@ class PyIndex : public std::enable_shared_from_this<PyIndex<dist_t, kType>> {
 
   // ---- additions for the GPU build (not in the reference) -------------------------------------
   void setDevice(int ordinal) { _index->setDevice(ordinal); }
+  void setDevices(const std::vector<int>& ordinals) { _index->setDevices(ordinals); }
+  std::vector<int> devices() { return _index->devices(); }
   void syncDevice() { _index->syncDevice(); }
   uintptr_t deviceHandle() { return reinterpret_cast<uintptr_t>(_index->deviceHandle()); }
   uint64_t currentNumNodes() { return _index->currentNumNodes(); }
@@ -213,7 +215,11 @@ void bindIndex(py::module_& m, const char* name) {
       .def_property_readonly("max_edges_per_node", &T::getMaxEdgesPerNode)
       .def_property_readonly("num_threads", &T::getNumThreads)
       // GPU-build additions
-      .def("set_device", &T::setDevice, py::arg("ordinal"), "GPU ordinal holding the device mirror.")
+      .def("set_device", &T::setDevice, py::arg("ordinal"), "Use this one GPU.")
+      .def("set_devices", &T::setDevices, py::arg("ordinals"),
+           "GPUs that each hold a replica of the index; batched searches are sharded over them (default: the "
+           "FLATNAV_DEVICES environment variable, else every visible GPU).")
+      .def_property_readonly("devices", &T::devices)
       .def("sync_device", &T::syncDevice, "Upload pending changes to HBM now instead of at the next search.")
       .def("device_handle", &T::deviceHandle, "fnv_index_t of the device mirror as an integer.")
       .def("_raw_blob", &T::rawBlob)

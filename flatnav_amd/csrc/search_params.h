@@ -16,7 +16,13 @@ constexpr int WAVE = 64;
 #ifndef FNV_PU
 #define FNV_PU 3
 #endif
-constexpr int PU = FNV_PU;  // vector "passes" whose loads are issued back to back before any use
+constexpr int PU_DEFAULT = FNV_PU;  // vector "passes" whose loads are issued back to back before any use
+// Rows of a whole number of 192-chunk spans (768-d, 1536-d float32 ...) run with G = 64, CU = 3 -- every lane loads
+// exactly its three chunks, no clamping -- and four vectors in flight: the same 12 loads per lane as PU_DEFAULT x 4.
+template <int G, int CU>
+constexpr int passes() {
+  return (G == 64 && CU == 3) ? 4 : PU_DEFAULT;
+}
 #ifndef FNV_MIN_WAVES_PER_SIMD
 #define FNV_MIN_WAVES_PER_SIMD 4  // __launch_bounds__ 2nd argument: register budget 512/4 = 128 per lane
 #endif

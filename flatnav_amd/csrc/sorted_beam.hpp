@@ -56,6 +56,7 @@ constexpr int NO_ENTRY = 1 << 30;               // WIDE: "no unexpanded entry" (
 #endif
 template <typename T, int METRIC, int G, int CU, bool FULL, bool WIDE>
 __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_sorted_kernel(const SearchParams p) {
+  constexpr int PU = passes<G, CU>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
   const float INF = std::numeric_limits<float>::infinity();

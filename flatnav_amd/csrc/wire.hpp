@@ -76,6 +76,7 @@ template <typename T, int METRIC, int G, int CU, bool FULL>
 __device__ __forceinline__ int prune_ordered(const WireParams& p, uint4* qlds, const float* okey, const uint32_t* oid,
                                              int C, int keep, uint32_t* alive, uint32_t* kept, uint32_t* stage_ids,
                                              uint32_t* stage_idx, int lane) {
+  constexpr int PU = passes<G, CU>();
   constexpr int VPW = WAVE / G;
   const int v = lane / G;
   for (int j = lane; j < C; j += WAVE) alive[j] = 1u;
@@ -134,6 +135,7 @@ __device__ __forceinline__ int prune_ordered(const WireParams& p, uint4* qlds, c
 template <typename T, int METRIC, int G, int CU, bool FULL>
 __device__ __forceinline__ void keys_from(const WireParams& p, uint4* qlds, uint32_t base, const uint32_t* cid, int C,
                                           float* ckey, int lane) {
+  constexpr int PU = passes<G, CU>();
   constexpr int VPW = WAVE / G;
   const int vgrp = lane / G;
   stage_vector(qlds, p.vectors, p.row_bytes, (int)p.nchunks, base, lane);

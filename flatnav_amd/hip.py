@@ -24,7 +24,8 @@ C_ABI_SYMBOLS = [
     "fnv_index_device_buffers", "fnv_index_info", "fnv_index_free", "fnv_set_option", "fnv_search_batch",
     "fnv_search_batch_device", "fnv_search_status", "fnv_last_kernel_ms", "fnv_last_launch_geometry",
     "fnv_index_set_live_nodes", "fnv_index_write_nodes", "fnv_index_write_links", "fnv_index_insert_batch",
-    "fnv_index_read_links", "fnv_last_replayed_queries",
+    "fnv_index_read_links", "fnv_last_replayed_queries", "fnv_replicate", "fnv_replica_refresh",
+    "fnv_search_batch_multi",
 ]
 
 _lib = None
@@ -70,6 +71,10 @@ def lib() -> C.CDLL:
     L.fnv_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.fnv_last_replayed_queries.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.fnv_last_launch_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.fnv_replicate.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+    L.fnv_replica_refresh.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.fnv_search_batch_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_int,
+                                         C.c_int] + [C.c_void_p] * 5
     _lib = L
     return L
 
@@ -94,6 +99,27 @@ def device_count() -> int:
 
 def _np_dtype(name: str):
     return {"float32": np.float32, "uint8": np.uint8, "int8": np.int8}[name]
+
+
+def search_multi(indexes, queries, K: int, ef_search: int, num_initializations: int = 100, stats: bool = False):
+    """One batch over several handles of the same index (replicas on several GPUs): rows [g*ceil(Q/G), ...) go to
+    indexes[g], all devices work concurrently -> (dist float32[Q,K], labels int32[Q,K][, stats])."""
+    first = indexes[0]
+    q = np.ascontiguousarray(queries, dtype=_np_dtype(first.dtype))
+    if q.ndim != 2 or q.shape[1] != first.dim:
+        raise ValueError("Queries have incorrect dimensions.")
+    nq = q.shape[0]
+    d = np.empty((nq, K), dtype=np.float32)
+    l = np.empty((nq, K), dtype=np.int32)
+    cnt = np.empty(nq, dtype=np.int32)
+    nd = np.zeros(nq, dtype=np.uint64)
+    nh = np.zeros(nq, dtype=np.uint64)
+    arr = (C.c_void_p * len(indexes))(*[ix._h for ix in indexes])
+    check(lib().fnv_search_batch_multi(arr, len(indexes), q.ctypes.data, nq, K, ef_search, num_initializations,
+                                       d.ctypes.data, l.ctypes.data, cnt.ctypes.data, nd.ctypes.data, nh.ctypes.data))
+    if stats:
+        return d, l, {"count": cnt, "n_dist": nd, "n_hops": nh}
+    return d, l
 
 
 class DeviceIndex:
@@ -180,6 +206,19 @@ class DeviceIndex:
         out = np.empty((int(count), self.M), dtype=np.uint32)
         check(lib().fnv_index_read_links(self._h, int(first_node), int(count), out.ctypes.data))
         return out
+
+    def replicate(self, devices) -> list:
+        """Replicas of this index on the given device ordinals (peer copies over xGMI); each is an independent handle."""
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        out = (C.c_void_p * len(devices))()
+        check(lib().fnv_replicate(self._h, len(devices), devs, out))
+        return [DeviceIndex(C.c_void_p(out[i])) for i in range(len(devices))]
+
+    def refresh_replicas(self, replicas) -> None:
+        arr = (C.c_void_p * len(replicas))(*[r._h for r in replicas])
+        check(lib().fnv_replica_refresh(self._h, len(replicas), arr))
+        for r in replicas:
+            r.n_nodes = self.n_nodes
 
     def set_option(self, name: str, value: int) -> None:
         check(lib().fnv_set_option(self._h, name.encode(), int(value)))

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -199,6 +200,11 @@ class Index {
   mutable size_t _device_synced_nodes = 0; // nodes [0, this) have their records on the device
   mutable detail::DirtyRows _dirty_rows;   // link rows of synced nodes that changed since
   int _device_ordinal = 0;
+  // several GPUs: the mirror on _device_ordinal is the primary; replicas of it live on the other devices of
+  // _device_list (filled by peer copies, refreshed whenever the primary changes); batches are sharded over all of them
+  mutable std::vector<int> _device_list;   // empty: not decided yet (FLATNAV_DEVICES, else every visible GPU)
+  mutable std::vector<fnv_index_t> _replicas;
+  mutable bool _replicas_stale = true;
 
   Index() = default;
   Index(const Index&) = delete;
@@ -373,6 +379,7 @@ class Index {
   // (fnv_index_write_links) -- unless that is most of the index anyway; otherwise the store is shipped whole.
   void ensureDevice() const {
     if (_device_index && !_device_stale) return;
+    resolveDeviceList();
     Index* self = const_cast<Index*>(this);
     const int metric = self->deviceMetric();
     const uint32_t dim = static_cast<uint32_t>(self->_distance->dimension());
@@ -396,6 +403,7 @@ class Index {
       if (_device_index) {
         fnv_index_free(_device_index);
         _device_index = nullptr;
+        dropReplicas();
       }
       if (_cur_num_nodes == _max_node_count) {  // complete: exactly as many rows as nodes
         detail::throwOnDeviceError(fnv_index_upload(_index_memory.get(), _node_size_bytes, _data_size_bytes,
@@ -416,6 +424,55 @@ class Index {
     }
     _device_synced_nodes = _cur_num_nodes;
     _device_stale = _device_rebuild = false;
+    _replicas_stale = true;
+  }
+
+  void dropReplicas() const {
+    for (fnv_index_t r : _replicas) fnv_index_free(r);
+    _replicas.clear();
+    _replicas_stale = true;
+  }
+
+  // The GPUs this index spreads its batches over: setDevices(), else the FLATNAV_DEVICES environment variable
+  // ("0,1,2,3"; an ordinal may repeat -- tests put two replicas on one GPU), else every visible device.
+  void resolveDeviceList() const {
+    if (!_device_list.empty()) return;
+    if (const char* env = std::getenv("FLATNAV_DEVICES")) {
+      std::stringstream ss(env);
+      for (std::string tok; std::getline(ss, tok, ',');)
+        if (!tok.empty()) _device_list.push_back(std::stoi(tok));
+    }
+    if (_device_list.empty()) {
+      int count = 1;
+      if (fnv_device_count(&count) != FNV_OK || count < 1) count = 1;
+      _device_list.push_back(_device_ordinal);
+      for (int d = 0; d < count; ++d)
+        if (d != _device_ordinal) _device_list.push_back(d);
+    }
+    const_cast<Index*>(this)->_device_ordinal = _device_list[0];
+  }
+
+  // Brings the replicas in line with the (up-to-date) primary mirror.
+  void ensureReplicas() const {
+    resolveDeviceList();
+    if (_device_list.size() <= 1) return;
+    if (!_replicas_stale && _replicas.size() + 1 == _device_list.size()) return;
+    if (_replicas.size() + 1 != _device_list.size()) {
+      dropReplicas();
+      _replicas.resize(_device_list.size() - 1, nullptr);
+      const int rc = fnv_replicate(_device_index, static_cast<int>(_replicas.size()), _device_list.data() + 1, _replicas.data());
+      if (rc != FNV_OK) {
+        _replicas.clear();
+        detail::throwOnDeviceError(rc);
+      }
+    } else {
+      const int rc = fnv_replica_refresh(_device_index, static_cast<int>(_replicas.size()), _replicas.data());
+      if (rc != FNV_OK) {  // e.g. the primary was re-created with another capacity: start over
+        dropReplicas();
+        return ensureReplicas();
+      }
+    }
+    _replicas_stale = false;
   }
 
   int deviceMetric() { return _distance->metricType() == MetricType::L2 ? FNV_METRIC_L2 : FNV_METRIC_IP; }
@@ -443,16 +500,28 @@ class Index {
   }
 
   ~Index() {
+    dropReplicas();
     if (_device_index) fnv_index_free(_device_index);
   }
 
   // ---- GPU placement (new) ------------------------------------------------------------------
-  void setDevice(int ordinal) {
+  void setDevice(int ordinal) { setDevices(std::vector<int>{ordinal}); }
+  // The GPUs that hold a copy of the index; batched searches are sharded over all of them (rows
+  // [g * ceil(Q/G), ...) to the g-th), like the reference shards a batch over host threads
+  // (bindings.cpp:198-211).  Default: FLATNAV_DEVICES, else every visible GPU.
+  void setDevices(const std::vector<int>& ordinals) {
+    if (ordinals.empty()) throw std::invalid_argument("setDevices: at least one device ordinal is required");
     std::lock_guard<std::mutex> g(_device_guard);
-    if (ordinal != _device_ordinal) {
-      _device_ordinal = ordinal;
-      markDeviceRebuild();
-    }
+    if (ordinals == _device_list) return;
+    dropReplicas();
+    if (ordinals[0] != _device_ordinal || _device_list.empty()) markDeviceRebuild();
+    _device_list = ordinals;
+    _device_ordinal = ordinals[0];
+  }
+  std::vector<int> devices() const {
+    std::lock_guard<std::mutex> g(_device_guard);
+    resolveDeviceList();
+    return _device_list;
   }
   int device() const { return _device_ordinal; }
   // Push pending host-side changes to HBM now (otherwise done lazily by the next search).
@@ -707,9 +776,20 @@ class Index {
     ensureDevice();
     std::vector<uint64_t> ndist;
     if (_collect_stats) ndist.resize(nq);
-    detail::throwOnDeviceError(fnv_search_batch(_device_index, queries, nq, K, ef_search, num_initializations, out_dist,
-                                                reinterpret_cast<int32_t*>(out_labels), out_count,
-                                                _collect_stats ? ndist.data() : nullptr, nullptr));
+    // small batches stay on the primary GPU; larger ones are sharded over every replica
+    const bool spread = _device_list.size() > 1 && nq >= 64 * _device_list.size();
+    if (spread) ensureReplicas();
+    if (spread && !_replicas.empty()) {
+      std::vector<fnv_index_t> all{_device_index};
+      all.insert(all.end(), _replicas.begin(), _replicas.end());
+      detail::throwOnDeviceError(fnv_search_batch_multi(all.data(), static_cast<int>(all.size()), queries, nq, K, ef_search,
+                                                        num_initializations, out_dist, reinterpret_cast<int32_t*>(out_labels),
+                                                        out_count, _collect_stats ? ndist.data() : nullptr, nullptr));
+    } else {
+      detail::throwOnDeviceError(fnv_search_batch(_device_index, queries, nq, K, ef_search, num_initializations, out_dist,
+                                                  reinterpret_cast<int32_t*>(out_labels), out_count,
+                                                  _collect_stats ? ndist.data() : nullptr, nullptr));
+    }
     if (_collect_stats) {
       // reference accounting: + num_initializations per query (Index.h:857-859), + 1 per neighbour
       // evaluation (Index.h:689-691)

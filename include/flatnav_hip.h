@@ -25,11 +25,14 @@
  *                           include/flatnav/util/Multithreading.h:19-48, becomes the GPU grid).
  *   out_ndist / out_nhops   Index::_distance_computations, Index.h:83, 689-691, 857-859
  *                           (kept per query instead of one shared atomic).
+ *   fnv_replicate / fnv_search_batch_multi
+ *                           the batch parallelism of the binding (bindings.cpp:198-211:
+ *                           executeInParallel over query rows on one shared index) across
+ *                           the GPUs of a node: index replicated by peer copies over xGMI at
+ *                           load, query rows sharded, no per-query collective.
  *   fnv_index_device_buffers / fnv_index_alloc
- *                           multi-GPU replication: the caller broadcasts the three
- *                           device buffers with RCCL (one ncclBroadcast each at load,
- *                           no per-query collective); the reference has no analogue
- *                           (single process, shared memory).
+ *                           the same for one-process-per-GPU callers: they broadcast the three
+ *                           device buffers with RCCL (one ncclBroadcast each at load).
  *
  * Status codes mirror the exception the reference would throw at that point:
  *   FNV_ERR_INVALID  -> std::invalid_argument (Python ValueError)
@@ -62,7 +65,7 @@ enum { FNV_METRIC_L2 = 0, FNV_METRIC_IP = 1 };
 /* Message of the last failing call on this thread (never NULL). */
 const char* fnv_last_error(void);
 
-/* Library / build identification, e.g. "flatnav_hip gfx950 r1". */
+/* Library / build identification, e.g. "flatnav_hip gfx950 r2". */
 const char* fnv_version(void);
 
 /* Number of visible HIP devices. */
@@ -181,6 +184,25 @@ int fnv_search_batch_device(fnv_index_t index, const void* d_queries, uint64_t n
                             int num_initializations, float* d_out_dist, int32_t* d_out_labels,
                             int32_t* d_out_count, uint64_t* d_out_ndist, uint64_t* d_out_nhops,
                             void* hip_stream);
+
+/* ---- several GPUs of one node: index replicated, query rows sharded, no per-query collective -------
+ * The reference parallelises a batch over host threads that share one index in memory (executeInParallel over rows,
+ * python-bindings/src/flatnav/bindings.cpp:198-211, include/flatnav/util/Multithreading.h:19-48); here every GPU
+ * holds a replica in its own HBM.
+ * fnv_replicate: allocates an index of the same geometry and capacity on each of devices[0..n) (NULL = 0..n-1; a
+ *   device may appear more than once and may be the source's own) and fills them from `src` with peer copies over
+ *   xGMI, as a doubling tree (1 -> 2 -> 4 -> 8 holders).  The replicas are independent handles (own workspace and
+ *   stream); free each with fnv_index_free.  One process drives all GPUs -- processes that own one GPU each
+ *   (torch.distributed) broadcast the buffers of fnv_index_device_buffers with RCCL instead.
+ * fnv_replica_refresh: copies the live rows of `src` into existing replicas again (after the source grew or was
+ *   re-wired).
+ * fnv_search_batch_multi: fnv_search_batch over several handles of the same index: rows [g*ceil(Q/G), ...) go to
+ *   indexes[g]; all devices work concurrently (per-device stream), results land in the caller's row ranges. */
+int fnv_replicate(fnv_index_t src, int n_devices, const int* devices, fnv_index_t* out);
+int fnv_replica_refresh(fnv_index_t src, int n_replicas, fnv_index_t* replicas);
+int fnv_search_batch_multi(fnv_index_t* indexes, int n_indexes, const void* queries, uint64_t nq, int K,
+                           int ef_search, int num_initializations, float* out_dist, int32_t* out_labels,
+                           int32_t* out_count, uint64_t* out_ndist, uint64_t* out_nhops);
 
 /* Wait for the most recent fnv_search_batch_device launch on this index and report whether any
  * query hit a capacity limit (FNV_ERR_CAPACITY); fnv_search_batch calls this itself. */

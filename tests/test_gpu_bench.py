@@ -45,3 +45,37 @@ def test_two_ranks_share_one_gpu_over_gloo():
     assert d["n_gpus"] == 2 and "cpu_baseline" not in d
     assert d["config"]["parallelism"].startswith("index replicated x2")
     assert d["config"]["recall_at_10"] >= 0.95 and d["value"] > 0
+
+
+def test_benchmark_harness_writes_the_reference_metrics(tmp_path):
+    # tools/run_benchmark.py: the reference's harness metrics (experiments/run-benchmark.py:38-124: recall, qps,
+    # latency percentiles, distance computations per query) for the GPU index, written as metrics.json
+    out_file = str(tmp_path / "metrics.json")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "run_benchmark.py"), "--synthetic", "sift", "--n", "20000",
+           "--num-queries", "300", "--k", "10", "--ef-search", "50", "100", "--single-query-samples", "50",
+           "--metrics-file", out_file, "--dataset-name", "sift-like-20k"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    exps = json.load(open(out_file))["sift-like-20k"]
+    assert len(exps) == 2
+    for e in exps:
+        for k in ("recall", "qps", "qps_batched", "latency_p50", "latency_p95", "latency_p99", "latency_p999",
+                  "distance_computations", "build_time", "index_size", "node_links", "ef_construction", "ef_search", "k"):
+            assert k in e, k
+        assert e["recall"] > 0.9 and e["qps"] > 0 and e["distance_computations"] > 100
+    assert exps[1]["recall"] >= exps[0]["recall"]
+
+
+def test_bench_spawns_its_own_ranks_and_runs_other_configs():
+    # `python bench.py --gpus 2` without a torch.distributed environment launches the two ranks itself; c4 (100-d
+    # inner product) exercises a configuration other than the default, at a reduced size
+    env = dict(os.environ, BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c4", "--index-size", "50000",
+           "--nq", "1000", "--steps", "2", "--warmup", "1", "--no-secondary"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["workload"].startswith("c4 ") and d["value"] > 0
+    assert d["roofline"]["frac_of_achievable"] > d["roofline"]["frac"] > 0

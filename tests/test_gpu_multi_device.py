@@ -1,0 +1,93 @@
+"""Several GPUs behind the drop-in API: index replicated by peer copies, query rows sharded, no
+per-query collective -- fnv_replicate / fnv_replica_refresh / fnv_search_batch_multi in the C ABI, Index::setDevices in
+the host API.  The GPU box has one device, so the replicas here live on the SAME GPU (a device may be listed twice):
+G = 1 and G = 2, 3 must return identical bytes.  (One process per GPU with RCCL broadcasts: tests/test_gpu_fullsize.py,
+tests/test_multigpu_cpu.py.)"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from flatnav_amd import datasets as ds
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_replicas_answer_like_the_source(oracle_mod):
+    from flatnav_amd import hip
+
+    X, Q = ds.sift_like(12000, 3001)  # odd batch: the last shard is shorter
+    o = oracle_mod.OracleIndex.create("l2", 128, 12000, 16)
+    o.add(X, 64, threads=4)
+    src = hip.DeviceIndex.upload(o.blob(), o.node_size, o.data_size, o.M, o.cur_nodes, "float32", "l2", 128)
+    want = src.search(Q, 10, 80, stats=True)
+    replicas = src.replicate([0, 0])
+    for G in (1, 2, 3):
+        got = hip.search_multi([src] + replicas[: G - 1], Q, 10, 80, stats=True)
+        for a, b in zip(want[:2], got[:2]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        for k in ("count", "n_dist", "n_hops"):
+            assert np.array_equal(want[2][k], got[2][k])
+    # fewer rows than handles, and an empty batch
+    d, l = hip.search_multi([src] + replicas, Q[:2], 10, 80)
+    assert np.array_equal(l, want[1][:2])
+    d, l = hip.search_multi([src] + replicas, Q[:0], 10, 80)
+    assert d.shape == (0, 10)
+    # the source changes (a link row is rewritten): replicas follow after a refresh, not before
+    row = np.arange(1, 17, dtype=np.uint32)[None, :]
+    src.write_links(np.array([0], dtype=np.uint32), row)
+    after = src.search(Q, 10, 80)
+    stale = replicas[0].search(Q, 10, 80)
+    src.refresh_replicas(replicas)
+    fresh = replicas[1].search(Q, 10, 80)
+    assert np.array_equal(after[1], fresh[1]) and np.array_equal(after[0], fresh[0])
+    assert np.array_equal(stale[1], want[1])
+    with pytest.raises(ValueError):
+        src.replicate([7])  # not a visible device
+
+
+def test_host_api_spreads_batches_over_its_devices(oracle_mod):
+    import flatnav_amd as flatnav
+
+    X, Q = ds.sift_like(15000, 2000)
+    one = flatnav.index.create("l2", 128, 15000, 16)
+    one.set_num_threads(4)
+    one.add(X, 64)
+    one.set_devices([0])
+    d1, l1 = one.search(Q, 10, 64)
+    assert one.devices == [0]
+    one.set_devices([0, 0, 0])  # three replicas on the one GPU
+    d3, l3 = one.search(Q, 10, 64)
+    assert np.array_equal(d1, d3) and np.array_equal(l1, l3) and one.devices == [0, 0, 0]
+    ds_, ls_ = one.search_single(Q[5], 10, 64)
+    assert np.array_equal(ls_, l1[5])
+    # the index grows: primary mirror and replicas are brought up to date before the next batch
+    two = flatnav.index.create("l2", 128, 15000, 16)
+    two.set_devices([0, 0])
+    two.add(X[:9000], 64)
+    two.search(Q, 10, 64)
+    two.add(X[9000:], 64, labels=list(range(9000, 15000)))
+    d2, l2 = two.search(Q, 10, 64)
+    o = oracle_mod.OracleIndex.from_blob("l2", "float32", 128, 15000, 15000, 16, np.asarray(two._raw_blob()))
+    od, ol = o.search(Q, 10, 64)
+    assert np.array_equal(l2, ol) and np.array_equal(d2, od)
+
+
+def test_flatnav_devices_environment_variable():
+    code = ("import numpy as np, flatnav_amd as f\n"
+            "from flatnav_amd import datasets as ds\n"
+            "X, Q = ds.sift_like(5000, 600)\n"
+            "ix = f.index.create('l2', 128, 5000, 16); ix.add(X, 48)\n"
+            "d, l = ix.search(Q, 5, 40)\n"
+            "print(ix.devices, int(l.astype(np.int64).sum()), float(d.sum()))\n")
+    outs = []
+    for env_devices in ("0", "0,0"):
+        env = dict(os.environ, FLATNAV_DEVICES=env_devices, PYTHONPATH=ROOT)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append(out.stdout.strip().splitlines()[-1])
+    assert outs[0].startswith("[0] ") and outs[1].startswith("[0, 0] ")
+    assert outs[0].split("] ")[1] == outs[1].split("] ")[1]

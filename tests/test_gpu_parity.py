@@ -237,7 +237,7 @@ def test_sorted_beam_kernel_stays_exact(oracle_mod, hipmod, case):
     # adaptive default: launches of >= 2048 queries are timed, both kernels get their samples, the faster one stays;
     # where (almost) every query ties that is the two-heap kernel.  Whatever runs, the bytes are the same.
     dev.set_option("sorted_beam", 2)
-    Qbig = np.tile(Q, (4, 1))
+    Qbig = np.tile(Q, (-(-2048 // len(Q)), 1))  # the tuner looks at launches of at least 2048 queries
     first, kernels = None, []
     for _ in range(7):
         got = dev.search(Qbig, 10, 100, stats=True)

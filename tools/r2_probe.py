@@ -32,6 +32,8 @@ else:
         X, Q = ds.sift_like(N, 10000); metric = "l2"
     elif kind == "glove":
         X, Q = ds.lowrank_normalized(N, 10000, dim=100, rank=24, seed=100); metric = "angular"
+    elif kind == "s3":
+        X, Q = ds.lowrank_normalized(N, 10000, dim=768, rank=32, seed=7712); metric = "angular"
     else:
         X, Q = ds.randn(N, 10000, 128, seed=50); metric = "l2"
     ix, dev = build(metric, X)
