@@ -445,7 +445,7 @@ def main() -> None:
                 "frac": main_m["achieved"] / HBM_PEAK_GBPS,
                 "frac_of_achievable": main_m["achieved"] / HBM_ACHIEVABLE_GBPS,
                 "traffic": None,
-                "traffic_recorded": recorded_traffic(args.config, N, NQ, EF),
+                "traffic_recorded": recorded_traffic(args.config, DT, N, NQ, EF),
                 "algorithmic_bytes_per_launch": main_m["bytes"],
                 "avg_kernel_ms": main_m["kernel_ms"],
             },
@@ -501,7 +501,7 @@ def exact_topk(torch, dev, q, K, N, DIM, DT, metric, block=250_000):
     return best_i
 
 
-def recorded_traffic(config, n, nq, ef):
+def recorded_traffic(config, dtype, n, nq, ef):
     """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate runs, corrected as MI355X_MICROARCH.md prescribes) -- a RECORDED number, labelled as such; None unless
     the committed passes profiled this very workload."""
@@ -511,7 +511,7 @@ def recorded_traffic(config, n, nq, ef):
         except (OSError, ValueError):
             continue
         for r in rec if isinstance(rec, list) else [rec]:
-            if (r.get("config", "c2"), r.get("n"), r.get("nq"), r.get("ef")) == (config, n, nq, ef):
+            if (r.get("config", "c2"), r.get("dtype", "float32"), r.get("n"), r.get("nq"), r.get("ef")) == (config, dtype, n, nq, ef):
                 return {"hbm_bytes_per_launch_corrected": r.get("hbm_bytes_per_launch_corrected"),
                         "source": "profiles/%s (recorded in an earlier rocprofv3 --pmc run, not in this run)" % name}
     return None

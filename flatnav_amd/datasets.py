@@ -1,9 +1,11 @@
 """Synthetic dataset generators used by bench.py and the tests.
 
 No dataset can be downloaded in this environment, so the SIFT-1M / GloVe / randn
-configurations of BASELINE.json are reproduced by the seeded generators that
-SURVEY.md section 8(d) specifies (the reference's CPU numbers in BASELINE.md were
-taken on exactly these).
+configurations of BASELINE.json are reproduced by seeded generators with the
+distributions that SURVEY.md section 8(d) specifies.  The streams are defined by THIS
+code (chunked generation consumes the random stream in a different order than one
+big call, see sift_like), so BASELINE.md's CPU numbers -- taken on the survey's own
+one-call generators -- are statistically, not bytewise, comparable.
 """
 from __future__ import annotations
 

@@ -1,20 +1,23 @@
 #!/bin/bash
-# Collects the round's profile set on the GPU box into gpurun_out/ (run through gpurun from the repo root):
-#   bench line, rocprofv3 --kernel-trace --stats of the same command, separate --pmc passes for HBM traffic
-#   (FETCH_SIZE / WRITE_SIZE, per swept ef) and SQ instruction-mix counters.
-# tools/summarise_profiles.py then condenses them into profiles/.
+# Collects the round's profile set on the GPU box into gpurun_out/profile_set (run through gpurun from the repo root):
+#   the bench line, rocprofv3 --kernel-trace --stats of the same command, separate --pmc passes for HBM traffic
+#   (FETCH_SIZE / WRITE_SIZE) and SQ instruction-mix / wait counters, for the float32 headline and the uint8 index.
+# tools/summarise_profiles.py <tag> then condenses them into profiles/.
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/profile_set
 rm -rf $O; mkdir -p $O
-python $R/bench.py > $O/bench.json 2> $O/bench.log
+python $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.log
 EF=$(python3 -c "import json;print(json.load(open('$O/bench.json'))['config']['ef_search'])")
 echo "selected ef=$EF"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python3 $R/bench.py --no-cpu-baseline --steps 5 --ef $EF > $O/trace.log 2>&1
-for ef in $(echo 50 60 $EF | tr ' ' '\n' | sort -un); do
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_ef$ef -o bench -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 --ef $ef > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_ef$ef -o bench -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 --ef $ef > /dev/null 2>&1
+QUICK="--no-cpu-baseline --no-secondary --sustain-seconds 0 --ef $EF"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python3 $R/bench.py $QUICK --steps 20 --warmup 5 > $O/trace.log 2>&1
+for dt in float32 uint8; do
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_$dt -o bench -- python3 $R/bench.py $QUICK --dtype $dt --steps 3 --warmup 5 > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_$dt -o bench -- python3 $R/bench.py $QUICK --dtype $dt --steps 3 --warmup 5 > /dev/null 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/sq_$dt -o bench -- python3 $R/bench.py $QUICK --dtype $dt --steps 3 --warmup 5 > /dev/null 2>&1
 done
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/sq -o bench -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 --ef $EF > /dev/null 2>&1
-ls $O
+python $R/bench.py --dtype uint8 --steps 20 --warmup 5 > $O/bench_uint8.json 2> $O/bench_uint8.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_uint8 -o bench -- python3 $R/bench.py $QUICK --dtype uint8 --steps 20 --warmup 5 > $O/trace_uint8.log 2>&1
+ls $O $O/trace | head -40
