@@ -85,9 +85,11 @@ __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_s
     unsigned long long* beam = reinterpret_cast<unsigned long long*>(smem + ca->off_nbr);
     stage_query<T>(qlds, vis, ovf_list, qi, true, lane);
     __syncthreads();
+    PH_MARK(0);
 
     float best_d;
     uint32_t entry = entry_point<T, METRIC, G, CU, FULL>(vectors, row_bytes, nchunks, qlds, qi, lane, best_d);
+    PH_MARK(1);
     // wave-uniform by construction; say so, or every loop below is compiled as divergent control flow
     best_d = rfl(best_d);
     entry = (uint32_t)rfl((int)entry);
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_s
         pend = -INF;
       }
       n_hops++;
+      PH_MARK(2);
       // link row of this node: already in registers if the previous hop guessed it; and guess the next one now
       // (the runner-up, unless this hop admits something closer) so that its row load overlaps this hop's gather
       uint32_t row0 = pre_row;
@@ -181,6 +184,7 @@ __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_s
         pre_node = node2;
         pre_row = lane < M ? links[(uint64_t)(uint32_t)node2 * (uint32_t)M + lane] : EMPTY_ID;
       }
+      PH_MARK(3);
 
       for (int m0 = 0; m0 < M; m0 += WAVE) {
         const bool act = m0 + lane < M;
@@ -194,6 +198,7 @@ __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_s
         const int nn = __popcll(newmask);
         stage_ids[isnew ? __popcll(newmask & ((1ull << lane) - 1ull)) : WAVE] = id;  // keeps link order
         wave_sync();
+        PH_MARK(4);
         if (nn == 0) continue;
         n_dist += nn;
 
@@ -212,6 +217,7 @@ __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_s
           }
           const int npass = min(PU, (nn - base + VPW - 1) / VPW);
           batch_dists<T, METRIC, G, CU, FULL>(vectors, row_bytes, nchunks, qlds, cid, npass, cd, lane);
+          PH_MARK(5);
 
           // admissions in link order (Index.h:667-705); superset filter first (max_dist never grows once full)
 #pragma unroll
@@ -271,6 +277,7 @@ __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_s
             }
             if (tie) break;
           }
+          PH_MARK(6);
         }
         wave_sync();  // stage_ids is rewritten by the next row chunk
         if (tie) break;
@@ -321,6 +328,7 @@ __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_s
       x.stage_ids = reinterpret_cast<uint32_t*>(smem + xa->off_stage_ids);
       x.ovf_list = reinterpret_cast<uint32_t*>(smem + xa->off_ovf);
       exact_query<T, METRIC, G, CU, FULL>(x, qi, entry, best_d, lane, ph);
+      PH_FLUSH;
       continue;
     } else {
       const int32_t* labels = c->labels;  // null: construction wants node ids
@@ -345,6 +353,8 @@ __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_s
       }
     }
     if (ovf) clear_spill_bitmap(bitmap, ovf_list, ovf_glist, true, lane);
+    PH_MARK(7);
+    PH_FLUSH;
     __syncthreads();
   }
 }

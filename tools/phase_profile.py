@@ -12,7 +12,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PROF_LIB = os.path.join(ROOT, "flatnav_amd", "libflatnav_hip_prof.so")
-PHASES = ["setup", "entry_scan", "pop(other)", "link_row", "visited", "distances", "admission(other)", "finalize",
+PHASES = ["setup", "entry_scan", "pop / select", "link_row", "visited", "distances", "admission(other)", "finalize",
           "candpop.choices", "candpop.chase", "candpop.fix", "candpush", "nbrpush", "nbrpop.choices", "nbrpop.chase",
           "nbrpop.fix"]
 
@@ -51,21 +51,28 @@ def main():
         dev.set_option(k, int(v))
     L = hip.lib()
     L.fnv_debug_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-    dev.search(Q, 10, args.ef)
-    buf = (C.c_uint64 * 16)()
-    L.fnv_debug_phase_cycles(dev._h, buf)  # reset after warm-up
-    _, _, st = dev.search(Q, 10, args.ef, stats=True)
-    ms = dev.last_kernel_ms()
-    L.fnv_debug_phase_cycles(dev._h, buf)
-    cyc = np.array(list(buf), dtype=np.float64)
-    hops = st["n_hops"].sum()
-    print("kernel %.3f ms, %.0f QPS (kernel only, with timing overhead), geometry %s" % (
-        ms, args.nq / ms * 1e3, dev.launch_geometry()))
-    print("%-18s %14s %12s %10s" % ("phase", "cycles/query", "cycles/hop", "share"))
-    for name, c in zip(PHASES, cyc):
-        print("%-18s %14.0f %12.1f %9.1f%%" % (name, c / args.nq, c / hops, 100 * c / cyc.sum()))
-    print("total cycles/query %.0f; hops/query %.1f; dist evals/query %.1f" % (
-        cyc.sum() / args.nq, hops / args.nq, st["n_dist"].mean()))
+    for nq in sorted({1, 64, args.nq}):
+        for kernel, opts in (("two heaps", {"sorted_beam": 0}), ("sorted beam", {"sorted_beam": 1})):
+            for k, v in opts.items():
+                dev.set_option(k, v)
+            dev.search(Q[:nq], 10, args.ef)
+            buf = (C.c_uint64 * 16)()
+            L.fnv_debug_phase_cycles(dev._h, buf)  # reset after warm-up
+            reps = 50 if nq == 1 else 1
+            hops = 0; ms = 0.0; nd = 0.0
+            for r in range(reps):
+                _, _, st = dev.search(Q[r:r + nq], 10, args.ef, stats=True)
+                ms += dev.last_kernel_ms(); hops += st["n_hops"].sum(); nd += st["n_dist"].sum()
+            L.fnv_debug_phase_cycles(dev._h, buf)
+            cyc = np.array(list(buf), dtype=np.float64)
+            nqt = nq * reps
+            print("\n%s, %d queries per launch, ef=%d: kernel %.3f ms per launch (with timing overhead), geometry %s" % (
+                kernel, nq, args.ef, ms / reps, dev.launch_geometry()))
+            print("%-18s %14s %12s %10s" % ("phase", "cycles/query", "cycles/hop", "share"))
+            for name, c in zip(PHASES, cyc):
+                if c:
+                    print("%-18s %14.0f %12.1f %9.1f%%" % (name, c / nqt, c / hops, 100 * c / cyc.sum()))
+            print("total cycles/query %.0f; hops/query %.1f; dist evals/query %.1f" % (cyc.sum() / nqt, hops / nqt, nd / nqt))
 
 
 if __name__ == "__main__":

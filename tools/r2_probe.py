@@ -15,10 +15,13 @@ def build(metric, X, M=32, efc=100):
 
 what = sys.argv[1] if len(sys.argv) > 1 else "reasons"
 if what == "reasons":
-    X, Q = ds.randn(20000, 600, 96, seed=4, normalize=True)
-    ix, dev = build("angular", X)
-    dev.set_option("register_beam", 0)
-    for K, ef in ((10, 100), (10, 65), (10, 64), (1, 1), (5, 17), (100, 100), (10, 128), (10, 129), (10, 200), (300, 300), (10, 1000)):
+    kind = sys.argv[2] if len(sys.argv) > 2 else "sift"
+    if kind == "sift":
+        X, Q = ds.sift_like(1_000_000, 10000); metric = "l2"
+    else:
+        X, Q = ds.lowrank_normalized(1_000_000, 10000, dim=100, rank=24, seed=100); metric = "angular"
+    ix, dev = build(metric, X)
+    for K, ef in ((10, 32), (10, 52), (10, 100), (10, 200), (10, 400), (10, 800), (100, 400)):
         dev.set_option("sorted_beam", 1)
         d, l, st = dev.search(Q, K, ef, stats=True)
         r = dev.replayed_queries()
