@@ -156,6 +156,7 @@ struct PinnedCall {
 };
 
 struct fnv_index_s {
+  bool owns_buffers = true;  // false: a view (fnv_index_view) of another handle's vectors / links / labels
   int device = 0;
   int dtype = FNV_DTYPE_FLOAT32, metric = FNV_METRIC_L2;
   uint32_t M = 0, dim = 0, row_bytes = 0;
@@ -375,6 +376,40 @@ int fnv_index_upload(const void* aos_blob, uint64_t node_size, uint64_t data_siz
   return FNV_OK;
 }
 
+int fnv_index_view(fnv_index_t src, fnv_index_t* out) {
+  if (!src || !out) return fail(FNV_ERR_INVALID, "null argument");
+  fnv_index_s* v = new fnv_index_s();
+  v->owns_buffers = false;
+  v->device = src->device;
+  v->dtype = src->dtype;
+  v->metric = src->metric;
+  v->M = src->M;
+  v->dim = src->dim;
+  v->row_bytes = src->row_bytes;
+  v->n_nodes = src->n_nodes;
+  v->capacity = src->capacity;
+  v->d_vectors = src->d_vectors;
+  v->d_links = src->d_links;
+  v->d_labels = src->d_labels;
+  v->visited_factor = src->visited_factor; v->visited_slots = src->visited_slots; v->visited_floor = src->visited_floor;
+  v->occupancy_target = src->occupancy_target; v->cand_factor = src->cand_factor; v->cand_slots = src->cand_slots;
+  v->spill_entries = src->spill_entries; v->blocks_per_cu = src->blocks_per_cu; v->visited_wide = src->visited_wide;
+  v->entry_kernel = src->entry_kernel; v->output_node_ids = src->output_node_ids; v->visited_tag_bits = src->visited_tag_bits;
+  v->register_beam = src->register_beam; v->sorted_beam = src->sorted_beam; v->sorted_beam_min = src->sorted_beam_min;
+  v->sorted_cand_lds = src->sorted_cand_lds; v->overflow_list = src->overflow_list;
+  if (hipSetDevice(v->device) != hipSuccess) {
+    delete v;
+    return fail(FNV_ERR_NO_DEVICE, "hipSetDevice failed");
+  }
+  int rc = index_common_init(v);
+  if (rc) {
+    fnv_index_free(v);
+    return rc;
+  }
+  *out = v;
+  return FNV_OK;
+}
+
 int fnv_index_device_buffers(fnv_index_t ix, void* ptrs[3], uint64_t sizes[3]) {
   if (!ix || !ptrs || !sizes) return fail(FNV_ERR_INVALID, "null argument");
   ptrs[0] = ix->d_vectors;
@@ -403,6 +438,7 @@ int fnv_index_free(fnv_index_t ix) {
   if (!ix) return FNV_OK;
   (void)hipSetDevice(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+  if (!ix->owns_buffers) ix->d_vectors = nullptr, ix->d_links = nullptr, ix->d_labels = nullptr;
   void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_bitmap, ix->d_ovf, ix->d_nodestage, ix->d_linkstage, ix->d_wirebuf, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase, ix->d_entry};
   for (void* b : bufs)
     if (b) (void)hipFree(b);

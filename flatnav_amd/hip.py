@@ -25,7 +25,7 @@ C_ABI_SYMBOLS = [
     "fnv_search_batch_device", "fnv_search_status", "fnv_last_kernel_ms", "fnv_last_launch_geometry",
     "fnv_index_set_live_nodes", "fnv_index_write_nodes", "fnv_index_write_links", "fnv_index_insert_batch",
     "fnv_index_read_links", "fnv_last_replayed_queries", "fnv_replicate", "fnv_replica_refresh",
-    "fnv_search_batch_multi",
+    "fnv_search_batch_multi", "fnv_index_view",
 ]
 
 _lib = None
@@ -71,6 +71,7 @@ def lib() -> C.CDLL:
     L.fnv_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.fnv_last_replayed_queries.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.fnv_last_launch_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.fnv_index_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.fnv_replicate.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
     L.fnv_replica_refresh.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     L.fnv_search_batch_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_int,
@@ -206,6 +207,12 @@ class DeviceIndex:
         out = np.empty((int(count), self.M), dtype=np.uint32)
         check(lib().fnv_index_read_links(self._h, int(first_node), int(count), out.ctypes.data))
         return out
+
+    def view(self) -> "DeviceIndex":
+        """A second handle on the same device buffers with its own workspace: two searches in flight on one index."""
+        h = C.c_void_p()
+        check(lib().fnv_index_view(self._h, C.byref(h)))
+        return DeviceIndex(h)
 
     def replicate(self, devices) -> list:
         """Replicas of this index on the given device ordinals (peer copies over xGMI); each is an independent handle."""

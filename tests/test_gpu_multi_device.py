@@ -91,3 +91,38 @@ def test_flatnav_devices_environment_variable():
         outs.append(out.stdout.strip().splitlines()[-1])
     assert outs[0].startswith("[0] ") and outs[1].startswith("[0, 0] ")
     assert outs[0].split("] ")[1] == outs[1].split("] ")[1]
+
+
+def test_index_view_shares_buffers_and_overlaps_launches(oracle_mod):
+    # fnv_index_view: a second handle on the same HBM buffers with its own workspace -- two searches in flight on one index
+    import torch
+
+    from flatnav_amd import hip
+
+    X, Q = ds.sift_like(12000, 4000)
+    o = oracle_mod.OracleIndex.create("l2", 128, 12000, 16)
+    o.add(X, 64, threads=4)
+    src = hip.DeviceIndex.upload(o.blob(), o.node_size, o.data_size, o.M, o.cur_nodes, "float32", "l2", 128)
+    view = src.view()
+    assert view.device_buffers() == src.device_buffers()
+    want = src.search(Q, 10, 64)
+    got = view.search(Q, 10, 64)
+    assert np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1])
+    # two launches in flight on two streams: each handle has its own dispenser / bitmaps / spill areas
+    dq = torch.from_numpy(Q).cuda()
+    outs = [(torch.empty((2000, 10), dtype=torch.float32, device="cuda"), torch.empty((2000, 10), dtype=torch.int32, device="cuda"))
+            for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for rep in range(4):
+        for i, h in enumerate((src, view)):
+            h.search_device(dq[i * 2000:(i + 1) * 2000].data_ptr(), 2000, 10, 64, 100, outs[i][0].data_ptr(), outs[i][1].data_ptr(),
+                            stream=streams[i].cuda_stream)
+    torch.cuda.synchronize()
+    src.status(); view.status()
+    for i in range(2):
+        assert np.array_equal(outs[i][1].cpu().numpy(), want[1][i * 2000:(i + 1) * 2000])
+        assert np.array_equal(outs[i][0].cpu().numpy(), want[0][i * 2000:(i + 1) * 2000])
+    view.close()
+    again = src.search(Q[:100], 10, 64)  # the source outlives its view
+    assert np.array_equal(again[1], want[1][:100])
