@@ -306,14 +306,21 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    settled = set()
+
     def run(ef, steps, warmup, min_seconds=0.0):
         """Times `steps` launches (batch i mod nb each); returns (elapsed, kernel_ms list, steps done)."""
         def step(i):
             dev.search_device(dq[i % nb].data_ptr(), NQ, K, ef, 100, d_dist.data_ptr(), d_lab.data_ptr(),
                               d_cnt.data_ptr(), d_nd.data_ptr(), d_nh.data_ptr(), stream=stream.cuda_stream)
+        if ef not in settled:  # the library's per-beam-width kernel choice: two timed samples of each of its (up to
+            settled.add(ef)    # three) variants, harvested by the following call -- set-up, like a JIT's first calls
+            for i in range(8):
+                step(i)
+                torch.cuda.synchronize()
         for i in range(warmup):
             step(i)
-            torch.cuda.synchronize()  # untimed; lets the library's kernel auto-choice see each warm-up launch's timing
+            torch.cuda.synchronize()  # untimed
         barrier()
         dev.status()
         evs = []

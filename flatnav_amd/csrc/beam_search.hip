@@ -170,13 +170,15 @@ struct fnv_index_s {
   int64_t visited_factor = 27, visited_slots = 0, visited_floor = 2048, occupancy_target = 13, cand_factor = 2,
           cand_slots = 0, spill_entries = 16384, blocks_per_cu = 0, visited_wide = 0,
           entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0, register_beam = 2, sorted_beam = 2,
-          sorted_beam_min = 1, sorted_cand_lds = 2;
+          sorted_beam_min = 1, sorted_cand_lds = 2, sorted_tail_exact_pct = -1;
   uint64_t options_version = 0;
   LaunchPlan plan;
-  // adaptive kernel choice ("sorted_beam" = 2): per beam width, the best time per query seen for each kernel
+  // adaptive kernel choice ("sorted_beam" = 2): per beam width, the best time per query seen for each variant
   struct Tuner {
-    float best[2] = {-1.f, -1.f};  // ms per query: [0] two-heap kernel, [1] sorted-beam kernel
-    int samples[2] = {0, 0};
+    // ms per query: [0] two-heap kernel, [1] sorted-beam kernel, [2] sorted-beam kernel whose last round of queries
+    // goes straight to the exact search ("sorted_tail_exact_pct" = 100; only launches of more than one round)
+    float best[3] = {-1.f, -1.f, -1.f};
+    int samples[3] = {0, 0, 0};
   };
   std::map<int, Tuner> tuner;
   int sample_B = 0, sample_kernel = -1;  // the launch between ev0 / ev1 is a sample for this entry (-1: it is not)
@@ -210,7 +212,7 @@ struct fnv_index_s {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t last_stream = nullptr;
   bool launched = false;
-  uint64_t geom[7] = {0, 0, 0, 0, 0, 0, 0};
+  uint64_t geom[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::mutex mu;       // launch configuration + workspace growth
   std::mutex host_mu;  // the host-buffer entry point owns d_q / d_out / stream for the whole call
 };
@@ -397,6 +399,7 @@ int fnv_index_view(fnv_index_t src, fnv_index_t* out) {
   v->entry_kernel = src->entry_kernel; v->output_node_ids = src->output_node_ids; v->visited_tag_bits = src->visited_tag_bits;
   v->register_beam = src->register_beam; v->sorted_beam = src->sorted_beam; v->sorted_beam_min = src->sorted_beam_min;
   v->sorted_cand_lds = src->sorted_cand_lds; v->overflow_list = src->overflow_list;
+  v->sorted_tail_exact_pct = src->sorted_tail_exact_pct;
   if (hipSetDevice(v->device) != hipSuccess) {
     delete v;
     return fail(FNV_ERR_NO_DEVICE, "hipSetDevice failed");
@@ -506,7 +509,8 @@ int fnv_index_write_links(fnv_index_t ix, const uint32_t* node_ids, const uint32
 int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   if (!ix || !name) return fail(FNV_ERR_INVALID, "null argument");
   std::string n(name);
-  if (value < 0) return fail(FNV_ERR_INVALID, "option values must be non-negative");
+  if (value < 0 && !(n == "sorted_tail_exact_pct" && value == -1))
+    return fail(FNV_ERR_INVALID, "option values must be non-negative");
   if (n == "visited_factor") ix->visited_factor = std::max<int64_t>(1, value);
   else if (n == "visited_slots") {
     if (value && (value & (value - 1)) && ((value % 3) || ((value / 3) & (value / 3 - 1))))
@@ -527,6 +531,7 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   else if (n == "sorted_beam") ix->sorted_beam = value;
   else if (n == "sorted_beam_min") ix->sorted_beam_min = value;
   else if (n == "sorted_cand_lds") ix->sorted_cand_lds = value;
+  else if (n == "sorted_tail_exact_pct") ix->sorted_tail_exact_pct = value;
   else if (n == "visited_tag_bits") ix->visited_tag_bits = value;
   else return fail(FNV_ERR_INVALID, "unknown option: " + n);
   ix->options_version++;
@@ -756,6 +761,15 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   // them anyway, harvested when a later call finds them complete, first one kernel, then the other, then the faster.
   bool sorted = plan.mode != MODE_HEAPS;
   bool sample = false;
+  int variant = sorted ? 1 : 0;
+  // The sorted-beam kernel's stragglers: a query that is searched twice finishes a whole exact-search latency late, and
+  // in the last round of a launch that lengthens the launch itself (one such query costs as much as hundreds).  With
+  // "sorted_tail_exact_pct" = p the last p % of one round of queries skip the sorted pass (the exact search is slower but
+  // never needs a second one): -15 % on the integer-valued SIFT stand-in at ef=52, +0-4 % on float data without ties --
+  // so by default (-1) it is one more variant that the adaptive choice measures.
+  const uint64_t round_slots = (uint64_t)plan.sbpc * (uint64_t)ix->num_cus;
+  const bool multi_round = sorted && nq > round_slots;
+  int64_t tail_pct = ix->sorted_tail_exact_pct < 0 ? 0 : ix->sorted_tail_exact_pct;
   if (sorted && ix->sorted_beam == 2) {
     if (ix->sample_kernel >= 0 && ix->launched && hipEventQuery(ix->ev1) == hipSuccess) {
       float ms = 0.f;
@@ -768,11 +782,19 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
       ix->sample_kernel = -1;
     }
     if (nq >= 2048) {
-      fnv_index_s::Tuner& t = ix->tuner[B];
-      if (t.samples[1] < 2) sorted = true;  // two samples each (the first launch of a kernel is a cold one)
-      else if (t.samples[0] < 2) sorted = false;
-      else sorted = t.best[1] <= t.best[0];
-      sample = t.samples[sorted ? 1 : 0] < 3;
+      fnv_index_s::Tuner& t = ix->tuner[2 * B + (multi_round ? 1 : 0)];
+      const bool try_tail = multi_round && ix->sorted_tail_exact_pct < 0;
+      // two samples each (the first launch of a kernel is a cold one), then the fastest
+      if (t.samples[1] < 2) variant = 1;
+      else if (t.samples[0] < 2) variant = 0;
+      else if (try_tail && t.samples[2] < 2) variant = 2;
+      else {
+        variant = t.best[1] <= t.best[0] ? 1 : 0;
+        if (try_tail && t.best[2] < t.best[variant]) variant = 2;
+      }
+      sample = t.samples[variant] < 3;
+      sorted = variant != 0;
+      if (variant == 2) tail_pct = 100;
     }
   }
   const int bpc = sorted ? plan.sbpc : plan.bpc;
@@ -808,6 +830,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   p.status = (int32_t*)(ix->d_dispenser + 1);
   p.redo_count = ix->d_dispenser + 3;  // [3] queries searched exactly after a tie, [4..7] by reason
   p.phase_cycles = ix->d_phase;
+  p.tail_exact = multi_round && sorted ? (uint32_t)std::min<uint64_t>((uint64_t)tail_pct * nslots / 100, nq) : 0u;
 
   HIP_TRY(hipMemsetAsync(ix->d_dispenser, 0, 8 * sizeof(uint32_t), stream));
   HIP_TRY(hipEventRecord(ix->ev0, stream));
@@ -833,8 +856,8 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   hipLaunchKernelGGL(kern, dim3(nslots), dim3(WAVE), lds_bytes, stream, p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ix->ev1, stream));
-  ix->sample_kernel = sample ? (sorted ? 1 : 0) : -1;
-  ix->sample_B = B;
+  ix->sample_kernel = sample ? variant : -1;
+  ix->sample_B = 2 * B + (multi_round ? 1 : 0);
   ix->sample_nq = nq;
   ix->last_stream = stream;
   ix->launched = true;
@@ -845,6 +868,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   ix->geom[4] = p.vis_slots;
   ix->geom[5] = p.cand_slots;
   ix->geom[6] = (uint64_t)(sorted ? plan.mode : MODE_HEAPS);
+  ix->geom[7] = p.tail_exact;
   return FNV_OK;
 }
 
@@ -1269,9 +1293,9 @@ int fnv_last_replayed_queries(fnv_index_t ix, uint64_t out[5]) {
   return FNV_OK;
 }
 
-int fnv_last_launch_geometry(fnv_index_t ix, uint64_t geom[7]) {
+int fnv_last_launch_geometry(fnv_index_t ix, uint64_t geom[8]) {
   if (!ix || !geom) return fail(FNV_ERR_INVALID, "null argument");
-  for (int i = 0; i < 7; i++) geom[i] = ix->geom[i];
+  for (int i = 0; i < 8; i++) geom[i] = ix->geom[i];
   return FNV_OK;
 }
 

@@ -111,16 +111,18 @@ __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_s
     else visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), vg, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
     ovf = __ballot(ovf) != 0ull;
     int tie = best_d != best_d ? 4 : 0;  // why the query is handed to the exact kernel (0 = it is not); NaN entry: 4
+    // The last queries of a launch go straight to the exact search: a query that is searched twice finishes a whole
+    // exact-search latency late, and in the last round of a launch that lengthens the launch itself (one such query
+    // costs as much as hundreds).  The exact search alone is slower than the sorted beam but never needs a second pass.
+    if ((uint32_t)qi + ca->tail_exact >= ca->nq) tie = 5;
     float amb = INF;  // (a) pending (+inf = none): a key at which the reference's eviction choice is unknown (see below)
     float pend = -INF;  // (b) pending (-inf = none): largest key at which two unexpanded members tied
     uint32_t n_dist = 0, n_hops = 0;
-    int pre_node = -1;      // node whose link row was loaded ahead of time (-1: none)
-    uint32_t pre_row = 0u;  // ... lane i: its i-th link
     __syncthreads();
 
     while (!tie) {
       // ---- pick the closest unexpanded member; (b) its runner-up must not have the same key -------------------
-      int node, node2 = -1;
+      int node;
       float key_c;
       if (!WIDE) {
         const unsigned long long valid = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
@@ -133,7 +135,6 @@ __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_s
         if (rest != 0ull) {
           const int c2 = __ffsll((long long)rest) - 1;
           if (readlane_f(kr, c2) == key_c) pend = fmaxf(pend, key_c);
-          node2 = __builtin_amdgcn_readlane((int)ir, c2);
         }
         expanded |= 1ull << c;
       } else {
@@ -152,7 +153,6 @@ __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_s
             const int l2 = __ffsll((long long)un) - 1;
             c2 = base + l2;
             if (readlane_f(w.key, l2) == key_c) pend = fmaxf(pend, key_c);
-            node2 = __builtin_amdgcn_readlane((int)w.val, l2);
             break;
           }
           base += WAVE;
@@ -175,15 +175,9 @@ __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_s
       }
       n_hops++;
       PH_MARK(2);
-      // link row of this node: already in registers if the previous hop guessed it; and guess the next one now
-      // (the runner-up, unless this hop admits something closer) so that its row load overlaps this hop's gather
-      uint32_t row0 = pre_row;
-      if (node != pre_node) row0 = lane < M ? links[(uint64_t)(uint32_t)node * (uint32_t)M + lane] : EMPTY_ID;
-      pre_node = -1;
-      if (node2 >= 0) {
-        pre_node = node2;
-        pre_row = lane < M ? links[(uint64_t)(uint32_t)node2 * (uint32_t)M + lane] : EMPTY_ID;
-      }
+      // link row of this node (requesting the likely NEXT node's row one hop ahead was tried: no gain for a lone
+      // query -- the instruction chain, not this latency, bounds it -- and -2 % with every slot busy)
+      const uint32_t row0 = lane < M ? links[(uint64_t)(uint32_t)node * (uint32_t)M + lane] : EMPTY_ID;
       PH_MARK(3);
 
       for (int m0 = 0; m0 < M; m0 += WAVE) {
@@ -302,7 +296,7 @@ __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_s
       }
     }
     if (tie) {  // search this query again, exactly (results, counters and clean-up are exact_query's)
-      if (lane == 0) {
+      if (lane == 0 && tie < 5) {
         uint32_t* rc = c->redo_count;
         atomicAdd(rc, 1u);
         atomicAdd(rc + tie, 1u);  // by reason: [1] eviction tie, [2] selection tie, [3] result tie, [4] NaN/inf

@@ -272,9 +272,10 @@ class DeviceIndex:
         return dict(zip(["total", "eviction_tie", "selection_tie", "result_tie", "nan_inf"], [int(x) for x in r]))
 
     def launch_geometry(self) -> dict:
-        g = (C.c_uint64 * 7)()
+        g = (C.c_uint64 * 8)()
         check(lib().fnv_last_launch_geometry(self._h, g))
         keys = ["grid_blocks", "block_threads", "lds_bytes", "blocks_per_cu", "visited_slots", "cand_slots"]
         out = {k: int(g[i]) for i, k in enumerate(keys)}
         out["kernel"] = ["two_heaps", "sorted_beam_registers", "sorted_beam_lds"][int(g[6])]
+        out["tail_exact"] = int(g[7])
         return out

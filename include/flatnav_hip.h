@@ -157,9 +157,13 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *   "sorted_beam"     the sorted-beam kernel (csrc/sorted_beam.hpp: the beam as one sorted array instead of the
  *                     reference's two heaps; a query in which equal distances meet at a decision is searched again
  *                     by the same wavefront with the exact two-heap code, so results are the same either way):
- *                     0 = never (two-heap kernel only), 1 = always, 2 (default) = adaptive -- used until more than a
- *                     fifth of a launch's queries needed the exact search (integer-valued data with wide beams),
- *                     then the two-heap kernel serves that beam width.  Needs capacity < 2^31 nodes.
+ *                     0 = never (two-heap kernel only), 1 = always, 2 (default) = adaptive -- launches of >= 2048
+ *                     queries are timed per beam width, first each variant twice, then the fastest serves that beam
+ *                     width (which one wins depends on how often the data ties).  Needs capacity < 2^31 nodes.
+ *   "sorted_tail_exact_pct"  the last p % of one round of queries (one round = as many queries as stay resident)
+ *                     of a sorted-beam launch go straight to the exact search: a query that is searched twice
+ *                     finishes late, and in the last round that lengthens the whole launch.  -1 (default) = one more
+ *                     variant for the adaptive choice to measure (0 or 100); >= 0 = fixed
  *   "sorted_beam_min" smallest beam width the sorted-beam kernel is used for (default 1)
  *   "sorted_cand_lds" where the exact re-run of the sorted-beam kernel keeps its candidates heap: 2 (default) = in LDS
  *                     when that costs neither resident queries nor visited-table slots, else in the slot's HBM spill
@@ -225,10 +229,11 @@ int fnv_last_kernel_ms(fnv_index_t index, float* ms);
  * selection tie, result tie, NaN/inf}; synchronises with that launch.  Results do not depend on it. */
 int fnv_last_replayed_queries(fnv_index_t index, uint64_t out[5]);
 
-/* Launch geometry of the most recent search: geom[7] = {grid_blocks, block_threads, lds_bytes,
+/* Launch geometry of the most recent search: geom[8] = {grid_blocks, block_threads, lds_bytes,
  * blocks_per_cu, visited_slots, cand_slots (LDS entries of the exact search's candidates heap), kernel: 0 = two-heap
- * kernel, 1 = sorted beam in registers, 2 = sorted beam in LDS}. */
-int fnv_last_launch_geometry(fnv_index_t index, uint64_t geom[7]);
+ * kernel, 1 = sorted beam in registers, 2 = sorted beam in LDS, tail_exact: the last that-many queries of the launch
+ * went straight to the exact search (sorted-beam kernels, see the "sorted_tail_exact_pct" option)}. */
+int fnv_last_launch_geometry(fnv_index_t index, uint64_t geom[8]);
 
 #ifdef __cplusplus
 }

@@ -251,6 +251,43 @@ def test_sorted_beam_kernel_stays_exact(oracle_mod, hipmod, case):
         assert kernels[-1] == "two_heaps"
 
 
+@pytest.mark.parametrize("case", ["sift_f32", "u8_ties"])
+def test_sorted_beam_tail_goes_straight_to_the_exact_search(oracle_mod, hipmod, case):
+    # "sorted_tail_exact_pct": the last queries of a launch of more than one round skip the sorted pass (a query that
+    # is searched twice in the last round lengthens the launch).  Which queries take which path must not show anywhere.
+    rng = np.random.default_rng(3)
+    if case == "u8_ties":
+        X = rng.integers(0, 4, (8000, 16)).astype(np.uint8); Q = rng.integers(0, 4, (9000, 16)).astype(np.uint8)
+        metric, dt, M = "l2", "uint8", 16
+    else:
+        X, Q = ds.sift_like(20000, 9000); metric, dt, M = "l2", "float32", 32
+    ix = _build(oracle_mod, metric, dt, X, M)
+    dev = _upload(hipmod, ix)
+    for ef in (52, 100):
+        want = ix.search(Q, 10, ef, stats=True)
+        dev.set_option("sorted_beam", 1)
+        for pct in (0, 37, 100, 1000):
+            dev.set_option("sorted_tail_exact_pct", pct)
+            got = dev.search(Q, 10, ef, stats=True)
+            g = dev.launch_geometry()
+            assert g["kernel"].startswith("sorted_beam") and g["grid_blocks"] < len(Q)
+            assert g["tail_exact"] == min(len(Q), pct * g["grid_blocks"] // 100)
+            _assert_exact(want, got)
+        # one round only: there is no tail
+        dev.search(Q[:1000], 10, ef)
+        assert dev.launch_geometry()["tail_exact"] == 0
+        # adaptive default: the tail is one more variant that gets measured; same bytes whichever runs
+        dev.set_option("sorted_tail_exact_pct", -1)
+        dev.set_option("sorted_beam", 2)
+        seen = set()
+        for _ in range(9):
+            _assert_exact(want, dev.search(Q, 10, ef, stats=True))
+            g = dev.launch_geometry()
+            seen.add((g["kernel"] == "two_heaps", g["tail_exact"] > 0))
+            dev.replayed_queries()  # synchronises: the launch's timing is complete when the next call looks at it
+        assert {(True, False), (False, False), (False, True)} <= seen
+
+
 def test_labels_and_duplicate_links(oracle_mod, hipmod):
     rng = np.random.default_rng(5)
     X = rng.integers(0, 256, (3000, 64)).astype(np.float32)

@@ -41,16 +41,14 @@ else:
         X, Q = ds.randn(N, 10000, 128, seed=50); metric = "l2"
     ix, dev = build(metric, X)
     for ef in (32, 52, 64, 100, 200, 400, 800):
-        for mode, opts in (("heaps", {"sorted_beam": 0}),
-                           ("sorted regs", {"sorted_beam": 1, "register_beam": 1}),
-                           ("sorted lds", {"sorted_beam": 1, "register_beam": 0}),
-                           ("adaptive", {"sorted_beam": 2, "register_beam": 1})):
-            if ef > 64 and mode == "sorted regs": continue
+        modes = [("heaps", {"sorted_beam": 0})]
+        for t in ((0, 50, 75, 100, 125, 150, 200) if ef <= 64 else (0, 12, 25, 50, 75)):
+            modes.append(("sorted t%d" % t, {"sorted_beam": 1, "register_beam": 1, "sorted_tail_exact_pct": t}))
+        for mode, opts in modes:
             for k, v in opts.items(): dev.set_option(k, v)
             dev.search(Q, 10, ef)
-            dev.replayed_queries()
             ts = []
-            for _ in range(3):
+            for _ in range(4):
                 dev.search(Q, 10, ef); ts.append(dev.last_kernel_ms())
             g = dev.launch_geometry()
-            print("ef=%d %-12s %.3f ms  %s bpc %d lds %d vis %d cand %d exact-reruns %s" % (ef, mode, min(ts), g["kernel"], g["blocks_per_cu"], g["lds_bytes"], g["visited_slots"], g["cand_slots"], dev.replayed_queries()["total"]), flush=True)
+            print("ef=%d %-12s %.3f ms  %s bpc %d exact-reruns %s" % (ef, mode, min(ts), g["kernel"], g["blocks_per_cu"], dev.replayed_queries()["total"]), flush=True)
