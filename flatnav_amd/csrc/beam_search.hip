@@ -43,6 +43,7 @@
 #ifdef FNV_DEV_FAST_BUILD
 #include "kernels.hpp"
 #include "sorted_beam.hpp"
+#include "merged_beam.hpp"
 #endif
 #include "relayout.hpp"
 
@@ -89,6 +90,7 @@ const KernelTable& kernel_table(int, int) {
         k.scan[c][f] = entry_scan_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
         k.sorted_regs[c][f] = beam_search_sorted_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, false>;
         k.sorted_lds[c][f] = beam_search_sorted_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, true>;
+        k.merged[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
         k.select[c][f] = wire_select_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
         k.connect[c][f] = wire_connect_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
       }
@@ -107,6 +109,7 @@ const KernelTable& kernel_table(int dtype, int metric) {
     fill_exact_##tag##_##mtag(tables[i]);       \
     fill_sorted_regs_##tag##_##mtag(tables[i]); \
     fill_sorted_lds_##tag##_##mtag(tables[i]);  \
+    fill_merged_##tag##_##mtag(tables[i]);      \
     fill_wire_##tag##_##mtag(tables[i]);        \
     i++;
     FNV_FOR_EACH_TYPE_METRIC(FNV_FILL)
@@ -119,9 +122,9 @@ const KernelTable& kernel_table(int dtype, int metric) {
 
 kernel_fn pick_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).exact[cfg][full]; }
 kernel_fn pick_scan_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).scan[cfg][full]; }
-kernel_fn pick_sorted_kernel(int dtype, int metric, int cfg, bool full, bool wide) {
+kernel_fn pick_sorted_kernel(int dtype, int metric, int cfg, bool full, int mode) {  // mode: MODE_* below, != 0
   const KernelTable& t = kernel_table(dtype, metric);
-  return wide ? t.sorted_lds[cfg][full] : t.sorted_regs[cfg][full];
+  return mode == 3 ? t.merged[cfg][full] : mode == 2 ? t.sorted_lds[cfg][full] : t.sorted_regs[cfg][full];
 }
 wire_fn pick_wire_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).select[cfg][full]; }
 wire_fn pick_connect_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).connect[cfg][full]; }
@@ -170,7 +173,7 @@ struct fnv_index_s {
   int64_t visited_factor = 27, visited_slots = 0, visited_floor = 2048, occupancy_target = 13, cand_factor = 2,
           cand_slots = 0, spill_entries = 16384, blocks_per_cu = 0, visited_wide = 0,
           entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0, register_beam = 2, sorted_beam = 2,
-          sorted_beam_min = 1, sorted_cand_lds = 2, sorted_tail_exact_pct = -1;
+          sorted_beam_min = 1, sorted_cand_lds = 2, sorted_tail_exact_pct = -1, merged_beam = 1;
   uint64_t options_version = 0;
   LaunchPlan plan;
   // adaptive kernel choice ("sorted_beam" = 2): per beam width, the best time per query seen for each variant
@@ -400,6 +403,7 @@ int fnv_index_view(fnv_index_t src, fnv_index_t* out) {
   v->register_beam = src->register_beam; v->sorted_beam = src->sorted_beam; v->sorted_beam_min = src->sorted_beam_min;
   v->sorted_cand_lds = src->sorted_cand_lds; v->overflow_list = src->overflow_list;
   v->sorted_tail_exact_pct = src->sorted_tail_exact_pct;
+  v->merged_beam = src->merged_beam;
   if (hipSetDevice(v->device) != hipSuccess) {
     delete v;
     return fail(FNV_ERR_NO_DEVICE, "hipSetDevice failed");
@@ -532,6 +536,7 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   else if (n == "sorted_beam_min") ix->sorted_beam_min = value;
   else if (n == "sorted_cand_lds") ix->sorted_cand_lds = value;
   else if (n == "sorted_tail_exact_pct") ix->sorted_tail_exact_pct = value;
+  else if (n == "merged_beam") ix->merged_beam = value;
   else if (n == "visited_tag_bits") ix->visited_tag_bits = value;
   else return fail(FNV_ERR_INVALID, "unknown option: " + n);
   ix->options_version++;
@@ -556,7 +561,7 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
 // ---- launch configuration ---------------------------------------------------------------------------------
 // How a query slot's LDS is laid out depends on the kernel: the two-heap kernel keeps {query, neighbours heap,
 // candidates heap, visited table, staging}; the sorted-beam kernels keep {query, [beam array], visited table, staging}.
-enum { MODE_HEAPS = 0, MODE_SORTED_REGS = 1, MODE_SORTED_LDS = 2 };
+enum { MODE_HEAPS = 0, MODE_SORTED_REGS = 1, MODE_SORTED_LDS = 2, MODE_MERGED = 3 };
 
 // Visited-table geometry for a table of `slots` (2^j or 3*2^j) and the LDS layout that follows from it; returns the
 // bytes of LDS one query slot needs.  16-bit tags whenever the per-bucket id range fits 14 bits: buckets =
@@ -600,6 +605,8 @@ static uint32_t lay_out(const fnv_index_s* ix, SearchParams& p, uint32_t slots, 
   off = align16(off + p.vis_bytes);
   p.off_stage_ids = off;
   off = align16(off + (WAVE + 1) * 4);  // + one write-only slot for lanes with nothing to stage
+  p.off_stage_d = off;
+  if (mode == MODE_MERGED) off = align16(off + (WAVE + 1) * 4);
   p.off_ovf = off;
   off = align16(off + (OVF_LIST + 2) * 4);
   return off;
@@ -730,8 +737,11 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     const bool tagged = plan.heaps.vis_tag16 != 0;
     const bool want = ix->sorted_beam != 0 && B >= ix->sorted_beam_min && ix->capacity < (1ull << 31);
     plan.mode = (!tagged || !want) ? MODE_HEAPS : (B <= WAVE && ix->register_beam != 0) ? MODE_SORTED_REGS : MODE_SORTED_LDS;
+    // "merged_beam": 1 = beams of 65...256 entries, 2 = every beam <= 256 -> the merged-beam kernel (merged_beam.hpp)
+    if (plan.mode != MODE_HEAPS && B <= fnv_dev::MB_MAX_BEAM && (ix->merged_beam >= 2 || (ix->merged_beam == 1 && B > WAVE)))
+      plan.mode = MODE_MERGED;
     if (plan.mode != MODE_HEAPS) {
-      plan.skern = pick_sorted_kernel(ix->dtype, ix->metric, cfg, full, plan.mode == MODE_SORTED_LDS);
+      plan.skern = pick_sorted_kernel(ix->dtype, ix->metric, cfg, full, plan.mode);
       // the exact re-run's candidates heap: in LDS if that costs neither resident queries nor visited-table
       // slots, else entirely in the slot's HBM spill area (slower for the few queries that need it)
       SearchParams with = p, without = p;

@@ -1,12 +1,13 @@
 // kernel_inst.hip -- one compilation = the instantiations of ONE kernel family for ONE (element type, metric):
 //   hipcc -c -DFNV_INST_T=float -DFNV_INST_TAG=f32 -DFNV_INST_METRIC=0 -DFNV_INST_MTAG=l2 -DFNV_INST_FAMILY=2 ...
-// families: 0 exact two-heap kernel + entry scan, 1 sorted beam in registers, 2 sorted beam in LDS, 3 wiring kernels.
-// flatnav_amd/build.py compiles the 24 combinations in parallel and links them with beam_search.hip.
+// families: 0 exact two-heap kernel + entry scan, 1 sorted beam in registers, 2 sorted beam in LDS, 3 wiring kernels,
+// 4 merged beam.  flatnav_amd/build.py compiles the 30 combinations in parallel and links them with beam_search.hip.
 #include <hip/hip_runtime.h>
 
 #include "kernel_table.h"
 #include "kernels.hpp"
 #include "sorted_beam.hpp"
+#include "merged_beam.hpp"
 #include "wire.hpp"
 
 #define FNV_CAT_(a, b, c, d, e) a##b##c##d##e
@@ -39,6 +40,8 @@ static void fill_rows(KernelTable& t) {
 #elif FNV_INST_FAMILY == 2
 #define FNV_COMMA_TRUE , true
   FNV_ROW(t.sorted_lds, beam_search_sorted_kernel, FNV_COMMA_TRUE)
+#elif FNV_INST_FAMILY == 4
+  FNV_ROW(t.merged, beam_search_merged_kernel)
 #else
   FNV_ROW(t.select, wire_select_kernel)
   FNV_ROW(t.connect, wire_connect_kernel)
@@ -51,6 +54,8 @@ void FNV_CAT(fill_exact_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 void FNV_CAT(fill_sorted_regs_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 #elif FNV_INST_FAMILY == 2
 void FNV_CAT(fill_sorted_lds_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
+#elif FNV_INST_FAMILY == 4
+void FNV_CAT(fill_merged_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 #else
 void FNV_CAT(fill_wire_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 #endif

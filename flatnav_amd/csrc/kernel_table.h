@@ -34,6 +34,7 @@ struct KernelTable {
   kernel_fn scan[kNumCfgs][2];         // entry_scan_kernel (K0)
   kernel_fn sorted_regs[kNumCfgs][2];  // beam_search_sorted_kernel, beam in registers
   kernel_fn sorted_lds[kNumCfgs][2];   // beam_search_sorted_kernel, beam in LDS
+  kernel_fn merged[kNumCfgs][2];       // beam_search_merged_kernel (beam <= 256 in registers, one merge per link row)
   wire_fn select[kNumCfgs][2];         // wire_select_kernel
   wire_fn connect[kNumCfgs][2];        // wire_connect_kernel
 };
@@ -47,6 +48,7 @@ struct KernelTable {
   void fill_exact_##tag##_##mtag(KernelTable& t);        \
   void fill_sorted_regs_##tag##_##mtag(KernelTable& t);  \
   void fill_sorted_lds_##tag##_##mtag(KernelTable& t);   \
+  void fill_merged_##tag##_##mtag(KernelTable& t);       \
   void fill_wire_##tag##_##mtag(KernelTable& t);
 FNV_FOR_EACH_TYPE_METRIC(FNV_DECLARE_FILLERS)
 #undef FNV_DECLARE_FILLERS

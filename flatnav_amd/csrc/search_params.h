@@ -27,6 +27,9 @@ constexpr int passes() {
 #define FNV_MIN_WAVES_PER_SIMD 4  // __launch_bounds__ 2nd argument: register budget 512/4 = 128 per lane
 #endif
 
+constexpr int MB_R = 4;                   // merged-beam kernel: 64-entry chunks of the beam held in registers
+constexpr int MB_MAX_BEAM = MB_R * WAVE;  // ... = the widest beam it serves
+
 enum : int { ST_OK = 0, ST_CAND_OVERFLOW = 1 };
 constexpr int SCAN_WAVES = 4;  // entry_scan_kernel (K0): waves per workgroup ...
 constexpr int SCAN_QPB = 32;   // ... and queries per workgroup
@@ -68,6 +71,7 @@ struct SearchParams {
   uint32_t off_ovf;        // LDS: [0] count, [1..OVF_LIST] ids that went to the HBM bitmap
   uint32_t cand_slots, spill_entries, bitmap_words, ovf_cap;
   uint32_t off_q, off_nbr, off_cand, off_vis, off_stage_ids;
+  uint32_t off_stage_d;     // LDS: [WAVE + 1] distances of a link row's unvisited neighbours (merged-beam kernel)
   uint32_t tail_exact;     // sorted-beam kernel: the last tail_exact queries of the launch skip the sorted pass
 };
 

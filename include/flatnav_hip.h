@@ -164,6 +164,10 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *                     of a sorted-beam launch go straight to the exact search: a query that is searched twice
  *                     finishes late, and in the last round that lengthens the whole launch.  -1 (default) = one more
  *                     variant for the adaptive choice to measure (0 or 100); >= 0 = fixed
+ *   "merged_beam"     the merged-beam kernel (csrc/merged_beam.hpp: the sorted beam held in registers for beams of up
+ *                     to 256 entries, one merge per link row instead of one insertion per admitted neighbour; same
+ *                     tie rules and exact re-run as the sorted-beam kernel, same results): 0 = never, 1 (default) =
+ *                     beams of 65...256 entries, 2 = every beam of at most 256 entries
  *   "sorted_beam_min" smallest beam width the sorted-beam kernel is used for (default 1)
  *   "sorted_cand_lds" where the exact re-run of the sorted-beam kernel keeps its candidates heap: 2 (default) = in LDS
  *                     when that costs neither resident queries nor visited-table slots, else in the slot's HBM spill
@@ -231,7 +235,7 @@ int fnv_last_replayed_queries(fnv_index_t index, uint64_t out[5]);
 
 /* Launch geometry of the most recent search: geom[8] = {grid_blocks, block_threads, lds_bytes,
  * blocks_per_cu, visited_slots, cand_slots (LDS entries of the exact search's candidates heap), kernel: 0 = two-heap
- * kernel, 1 = sorted beam in registers, 2 = sorted beam in LDS, tail_exact: the last that-many queries of the launch
+ * kernel, 1 = sorted beam in registers, 2 = sorted beam in LDS, 3 = merged beam, tail_exact: the last that-many queries of the launch
  * went straight to the exact search (sorted-beam kernels, see the "sorted_tail_exact_pct" option)}. */
 int fnv_last_launch_geometry(fnv_index_t index, uint64_t geom[8]);
 

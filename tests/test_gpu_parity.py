@@ -146,6 +146,9 @@ def test_spill_paths_stay_exact(oracle_mod, hipmod):
     dev.set_option("visited_slots", 256)  # 16-bit-tag table, 64 buckets: most ids end up in the bitmap
     dev.set_option("sorted_beam", 1)  # sorted-beam kernel, exact re-run of the queries with ties
     _assert_exact(o, dev.search(Q, 10, 100, stats=True))
+    assert dev.launch_geometry()["kernel"] == "merged_beam"
+    dev.set_option("merged_beam", 0)
+    _assert_exact(o, dev.search(Q, 10, 100, stats=True))
     assert dev.launch_geometry()["kernel"] == "sorted_beam_lds"
     dev.set_option("sorted_beam", 0)  # from here on the two-heap kernel alone: its spill paths are the subject
     _assert_exact(o, dev.search(Q, 10, 100, stats=True))
@@ -189,7 +192,8 @@ def test_wide_tag_visited_tables_stay_exact(oracle_mod, hipmod, dt):
 
 @pytest.mark.parametrize("case", ["u8_ties", "sift_f32", "randn_ip", "i8_ip"])
 def test_sorted_beam_kernel_stays_exact(oracle_mod, hipmod, case):
-    # Sorted-beam kernel (default): the beam as one sorted array -- in registers for beams <= 64, else in LDS.  A
+    # Sorted-beam kernels (default): the beam as one sorted array -- in registers for beams <= 64, else in LDS -- or,
+    # merged-beam kernel, in registers for beams <= 256 with one merge per link row instead of one-by-one insertion.  A
     # query in which equal keys meet at a decision is searched again by the same wave with the exact two-heap code
     # (candidates heap in LDS or, when LDS is short, in the HBM spill area); ids, distances, counts and the per-query
     # counters must equal the two-heap kernel's and the oracle's bit for bit.
@@ -214,10 +218,14 @@ def test_sorted_beam_kernel_stays_exact(oracle_mod, hipmod, case):
         if case != "randn_ip":
             _assert_exact(ix.search(Q, K, ef, stats=True), want)
         dev.set_option("sorted_beam", 1)
-        forms = [(1, "sorted_beam_registers" if max(K, ef) <= 64 else "sorted_beam_lds", 2), (0, "sorted_beam_lds", 2),
-                 (0, "sorted_beam_lds", 0), (1, None, 1)]
-        for regs, kernel, cand_lds in forms:
+        wide = max(K, ef) > 256  # the merged-beam kernel (beam in registers, one merge per link row) serves <= 256
+        forms = [(1, "sorted_beam_registers" if max(K, ef) <= 64 else "sorted_beam_lds", 2, 0), (0, "sorted_beam_lds", 2, 0),
+                 (0, "sorted_beam_lds", 0, 0), (1, None, 1, 0), (1, "sorted_beam_lds" if wide else "merged_beam", 2, 2),
+                 (0, "sorted_beam_lds" if wide else "merged_beam", 0, 2),
+                 (1, "merged_beam" if 64 < max(K, ef) <= 256 else None, 2, 1)]
+        for regs, kernel, cand_lds, merged in forms:
             dev.set_option("register_beam", regs)
+            dev.set_option("merged_beam", merged)
             dev.set_option("sorted_cand_lds", cand_lds)  # 0: the exact re-run keeps its candidates heap in HBM
             got = dev.search(Q, K, ef, stats=True)
             g = dev.launch_geometry()
@@ -246,7 +254,7 @@ def test_sorted_beam_kernel_stays_exact(oracle_mod, hipmod, case):
         if first is None:
             first = got
         _assert_exact(first, got)
-    assert kernels[0] == "sorted_beam_lds" and "two_heaps" in kernels
+    assert kernels[0] == "merged_beam" and "two_heaps" in kernels
     if case == "u8_ties":
         assert kernels[-1] == "two_heaps"
 
@@ -270,7 +278,7 @@ def test_sorted_beam_tail_goes_straight_to_the_exact_search(oracle_mod, hipmod, 
             dev.set_option("sorted_tail_exact_pct", pct)
             got = dev.search(Q, 10, ef, stats=True)
             g = dev.launch_geometry()
-            assert g["kernel"].startswith("sorted_beam") and g["grid_blocks"] < len(Q)
+            assert g["kernel"] in ("sorted_beam_registers", "merged_beam") and g["grid_blocks"] < len(Q)
             assert g["tail_exact"] == min(len(Q), pct * g["grid_blocks"] // 100)
             _assert_exact(want, got)
         # one round only: there is no tail
