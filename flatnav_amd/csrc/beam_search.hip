@@ -90,7 +90,8 @@ const KernelTable& kernel_table(int, int) {
         k.scan[c][f] = entry_scan_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
         k.sorted_regs[c][f] = beam_search_sorted_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, false>;
         k.sorted_lds[c][f] = beam_search_sorted_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, true>;
-        k.merged[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
+        k.merged[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, MB_R>;
+        k.merged1[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, 1>;
         k.select[c][f] = wire_select_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
         k.connect[c][f] = wire_connect_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
       }
@@ -110,6 +111,7 @@ const KernelTable& kernel_table(int dtype, int metric) {
     fill_sorted_regs_##tag##_##mtag(tables[i]); \
     fill_sorted_lds_##tag##_##mtag(tables[i]);  \
     fill_merged_##tag##_##mtag(tables[i]);      \
+    fill_merged1_##tag##_##mtag(tables[i]);     \
     fill_wire_##tag##_##mtag(tables[i]);        \
     i++;
     FNV_FOR_EACH_TYPE_METRIC(FNV_FILL)
@@ -122,9 +124,9 @@ const KernelTable& kernel_table(int dtype, int metric) {
 
 kernel_fn pick_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).exact[cfg][full]; }
 kernel_fn pick_scan_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).scan[cfg][full]; }
-kernel_fn pick_sorted_kernel(int dtype, int metric, int cfg, bool full, int mode) {  // mode: MODE_* below, != 0
+kernel_fn pick_sorted_kernel(int dtype, int metric, int cfg, bool full, int mode, int B) {  // mode: MODE_* below, != 0
   const KernelTable& t = kernel_table(dtype, metric);
-  return mode == 3 ? t.merged[cfg][full] : mode == 2 ? t.sorted_lds[cfg][full] : t.sorted_regs[cfg][full];
+  return mode == 3 ? (B <= WAVE ? t.merged1[cfg][full] : t.merged[cfg][full]) : mode == 2 ? t.sorted_lds[cfg][full] : t.sorted_regs[cfg][full];
 }
 wire_fn pick_wire_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).select[cfg][full]; }
 wire_fn pick_connect_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).connect[cfg][full]; }
@@ -173,7 +175,7 @@ struct fnv_index_s {
   int64_t visited_factor = 27, visited_slots = 0, visited_floor = 2048, occupancy_target = 13, cand_factor = 2,
           cand_slots = 0, spill_entries = 16384, blocks_per_cu = 0, visited_wide = 0,
           entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0, register_beam = 2, sorted_beam = 2,
-          sorted_beam_min = 1, sorted_cand_lds = 2, sorted_tail_exact_pct = -1, merged_beam = 1;
+          sorted_beam_min = 1, sorted_cand_lds = 2, sorted_tail_exact_pct = -1, merged_beam = 2;
   uint64_t options_version = 0;
   LaunchPlan plan;
   // adaptive kernel choice ("sorted_beam" = 2): per beam width, the best time per query seen for each variant
@@ -598,15 +600,15 @@ static uint32_t lay_out(const fnv_index_s* ix, SearchParams& p, uint32_t slots, 
   off = align16(off + p.q_chunks * 16);
   // neighbours heap (exact search) / sorted beam: arrays start at 16n + 8 so that child pairs are 16-byte aligned
   p.off_nbr = off + 8;
-  off = align16(off + 8 + ((uint32_t)p.B + 2) * 8);
+  // (merged-beam kernel: the same bytes stage a link row's distances, [WAVE + 1] floats, between two merges)
+  off = align16(off + 8 + std::max<uint32_t>(((uint32_t)p.B + 2) * 8, mode == MODE_MERGED ? (WAVE + 1) * 4 : 0));
+  p.off_stage_d = p.off_nbr;
   p.off_cand = off + 8;  // candidates heap of the exact search: cand_slots entries in LDS (0: all of it in HBM)
   if (p.cand_slots) off = align16(off + 8 + (p.cand_slots + 1) * 8);
   p.off_vis = off;
   off = align16(off + p.vis_bytes);
   p.off_stage_ids = off;
   off = align16(off + (WAVE + 1) * 4);  // + one write-only slot for lanes with nothing to stage
-  p.off_stage_d = off;
-  if (mode == MODE_MERGED) off = align16(off + (WAVE + 1) * 4);
   p.off_ovf = off;
   off = align16(off + (OVF_LIST + 2) * 4);
   return off;
@@ -741,7 +743,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     if (plan.mode != MODE_HEAPS && B <= fnv_dev::MB_MAX_BEAM && (ix->merged_beam >= 2 || (ix->merged_beam == 1 && B > WAVE)))
       plan.mode = MODE_MERGED;
     if (plan.mode != MODE_HEAPS) {
-      plan.skern = pick_sorted_kernel(ix->dtype, ix->metric, cfg, full, plan.mode);
+      plan.skern = pick_sorted_kernel(ix->dtype, ix->metric, cfg, full, plan.mode, B);
       // the exact re-run's candidates heap: in LDS if that costs neither resident queries nor visited-table
       // slots, else entirely in the slot's HBM spill area (slower for the few queries that need it)
       SearchParams with = p, without = p;

@@ -1,7 +1,7 @@
 // kernel_inst.hip -- one compilation = the instantiations of ONE kernel family for ONE (element type, metric):
 //   hipcc -c -DFNV_INST_T=float -DFNV_INST_TAG=f32 -DFNV_INST_METRIC=0 -DFNV_INST_MTAG=l2 -DFNV_INST_FAMILY=2 ...
 // families: 0 exact two-heap kernel + entry scan, 1 sorted beam in registers, 2 sorted beam in LDS, 3 wiring kernels,
-// 4 merged beam.  flatnav_amd/build.py compiles the 30 combinations in parallel and links them with beam_search.hip.
+// 4 merged beam (<= 256 entries), 5 merged beam (<= 64 entries).  flatnav_amd/build.py compiles the 36 combinations in parallel and links them with beam_search.hip.
 #include <hip/hip_runtime.h>
 
 #include "kernel_table.h"
@@ -41,7 +41,11 @@ static void fill_rows(KernelTable& t) {
 #define FNV_COMMA_TRUE , true
   FNV_ROW(t.sorted_lds, beam_search_sorted_kernel, FNV_COMMA_TRUE)
 #elif FNV_INST_FAMILY == 4
-  FNV_ROW(t.merged, beam_search_merged_kernel)
+#define FNV_COMMA_MB_R , MB_R
+  FNV_ROW(t.merged, beam_search_merged_kernel, FNV_COMMA_MB_R)
+#elif FNV_INST_FAMILY == 5
+#define FNV_COMMA_ONE , 1
+  FNV_ROW(t.merged1, beam_search_merged_kernel, FNV_COMMA_ONE)
 #else
   FNV_ROW(t.select, wire_select_kernel)
   FNV_ROW(t.connect, wire_connect_kernel)
@@ -56,6 +60,8 @@ void FNV_CAT(fill_sorted_regs_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t
 void FNV_CAT(fill_sorted_lds_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 #elif FNV_INST_FAMILY == 4
 void FNV_CAT(fill_merged_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
+#elif FNV_INST_FAMILY == 5
+void FNV_CAT(fill_merged1_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 #else
 void FNV_CAT(fill_wire_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 #endif

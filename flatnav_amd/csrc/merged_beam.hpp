@@ -1,7 +1,7 @@
 // merged_beam.hpp -- part of the gfx950 search engine (device code; included only by beam_search.hip / kernel_inst.hip).
 //
 // beam_search_merged_kernel: the sorted-beam search (sorted_beam.hpp: same traversal as the reference's two heaps,
-// same tie rules, same in-wave exact re-run) for beams of up to 256 entries, with
+// same tie rules, same in-wave exact re-run) for beams of up to R * 64 entries (instantiated for R = 4 and R = 1), with
 //   * the beam RESIDENT IN REGISTERS: entry e lives in lane e % 64 of register pair (kr, ir)[e / 64], closest first;
 //     bit 31 of the id word is the "expanded" flag, entries beyond the beam's size hold {+inf, EMPTY_ID} (whose bit
 //     31 is set, so they never look unexpanded);
@@ -37,29 +37,31 @@ __device__ __forceinline__ uint32_t float_ord(float f) {
 
 // lane l of the (wave-uniform) r-th register of a small array, as a scalar.  One v_readlane per register and scalar
 // selects: a select over the registers themselves makes the compiler keep the array in scratch memory.
-__device__ __forceinline__ int lane_of(const uint32_t (&a)[MB_R], int r, int l) {
+template <int R>
+__device__ __forceinline__ int lane_of(const uint32_t (&a)[R], int r, int l) {
   int s = __builtin_amdgcn_readlane((int)a[0], l);
 #pragma unroll
-  for (int k = 1; k < MB_R; k++) {
+  for (int k = 1; k < R; k++) {
     const int t = __builtin_amdgcn_readlane((int)a[k], l);
     s = r == k ? t : s;
   }
   return s;
 }
-__device__ __forceinline__ float lane_of(const float (&a)[MB_R], int r, int l) {
+template <int R>
+__device__ __forceinline__ float lane_of(const float (&a)[R], int r, int l) {
   int s = __builtin_amdgcn_readlane(__float_as_int(a[0]), l);
 #pragma unroll
-  for (int k = 1; k < MB_R; k++) {
+  for (int k = 1; k < R; k++) {
     const int t = __builtin_amdgcn_readlane(__float_as_int(a[k]), l);
     s = r == k ? t : s;
   }
   return __int_as_float(s);
 }
 
-template <typename T, int METRIC, int G, int CU, bool FULL>
-__global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_merged_kernel(const SearchParams p) {
+template <typename T, int METRIC, int G, int CU, bool FULL, int R>
+__global__ __launch_bounds__(WAVE, (CU == 1 && R == 1) ? 5 : FNV_SORTED_WAVES_PER_SIMD) void beam_search_merged_kernel(const SearchParams p) {
+  // (128-byte rows, one-chunk beam: 97 registers as compiled for four waves per SIMD -- one over the budget of five)
   constexpr int PU = passes<G, CU>();
-  constexpr int R = MB_R;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
   const float INF = std::numeric_limits<float>::infinity();
@@ -73,13 +75,13 @@ __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_m
     const uint32_t* const links = ca->links;
     const uint32_t row_bytes = ca->row_bytes;
     const int nchunks = (int)ca->nchunks;
-    const int B = ca->B;  // <= MB_MAX_BEAM
+    const int B = ca->B;  // <= R * WAVE
     const int M = (int)ca->M;
     const VisGeom vg{ca->vis_nmask, ca->vis_rshift, ca->vis_rmask, ca->vis_mult, ca->vis_w};
     uint4* qlds = reinterpret_cast<uint4*>(smem + ca->off_q);
     uint32_t* vis = reinterpret_cast<uint32_t*>(smem + ca->off_vis);
     uint32_t* stage_ids = reinterpret_cast<uint32_t*>(smem + ca->off_stage_ids);
-    float* stage_d = reinterpret_cast<float*>(smem + ca->off_stage_d);
+    float* stage_d = reinterpret_cast<float*>(smem + ca->off_stage_d);  // aliases `beam` below: used between merges
     uint32_t* ovf_list = reinterpret_cast<uint32_t*>(smem + ca->off_ovf);
     // [B + 2] at 16n + 8 (word -1 = write-only bin): the merge's permutation buffer, and the neighbours heap of an
     // exact re-run

@@ -71,7 +71,8 @@ struct SearchParams {
   uint32_t off_ovf;        // LDS: [0] count, [1..OVF_LIST] ids that went to the HBM bitmap
   uint32_t cand_slots, spill_entries, bitmap_words, ovf_cap;
   uint32_t off_q, off_nbr, off_cand, off_vis, off_stage_ids;
-  uint32_t off_stage_d;     // LDS: [WAVE + 1] distances of a link row's unvisited neighbours (merged-beam kernel)
+  uint32_t off_stage_d;     // LDS: [WAVE + 1] distances of a link row's unvisited neighbours (merged-beam kernel; = off_nbr:
+                            // the permutation buffer is idle while they are staged)
   uint32_t tail_exact;     // sorted-beam kernel: the last tail_exact queries of the launch skip the sorted pass
 };
 

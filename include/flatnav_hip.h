@@ -166,8 +166,8 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *                     variant for the adaptive choice to measure (0 or 100); >= 0 = fixed
  *   "merged_beam"     the merged-beam kernel (csrc/merged_beam.hpp: the sorted beam held in registers for beams of up
  *                     to 256 entries, one merge per link row instead of one insertion per admitted neighbour; same
- *                     tie rules and exact re-run as the sorted-beam kernel, same results): 0 = never, 1 (default) =
- *                     beams of 65...256 entries, 2 = every beam of at most 256 entries
+ *                     tie rules and exact re-run as the sorted-beam kernel, same results): 0 = never, 1 = beams of
+ *                     65...256 entries, 2 (default) = every beam of at most 256 entries
  *   "sorted_beam_min" smallest beam width the sorted-beam kernel is used for (default 1)
  *   "sorted_cand_lds" where the exact re-run of the sorted-beam kernel keeps its candidates heap: 2 (default) = in LDS
  *                     when that costs neither resident queries nor visited-table slots, else in the slot's HBM spill
