@@ -405,7 +405,7 @@ def main() -> None:
                               "roofline_frac": m2["achieved"] / HBM_PEAK_GBPS,
                               "achieved_GBps": m2["achieved"], "mean_dist_evals_per_query": m2["nd"]})
     if rank == 0:
-        kname = {"two_heaps": "fnv_dev::beam_search_kernel", "sorted_beam_registers": "fnv_dev::beam_search_sorted_kernel",
+        kname = {"two_heaps": "fnv_dev::beam_search_kernel",
                  "sorted_beam_lds": "fnv_dev::beam_search_sorted_kernel",
                  "merged_beam": "fnv_dev::beam_search_merged_kernel"}[geom["kernel"]]
         out = {

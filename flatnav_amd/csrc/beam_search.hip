@@ -88,8 +88,7 @@ const KernelTable& kernel_table(int, int) {
       for (int f = 0; f < 2; f++) {
         k.exact[c][f] = beam_search_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
         k.scan[c][f] = entry_scan_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
-        k.sorted_regs[c][f] = beam_search_sorted_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, false>;
-        k.sorted_lds[c][f] = beam_search_sorted_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, true>;
+        k.sorted_lds[c][f] = beam_search_sorted_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
         k.merged[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, MB_R>;
         k.merged1[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, 1>;
         k.select[c][f] = wire_select_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
@@ -108,7 +107,6 @@ const KernelTable& kernel_table(int dtype, int metric) {
     int i = 0;
 #define FNV_FILL(T, tag, M, mtag)              \
     fill_exact_##tag##_##mtag(tables[i]);       \
-    fill_sorted_regs_##tag##_##mtag(tables[i]); \
     fill_sorted_lds_##tag##_##mtag(tables[i]);  \
     fill_merged_##tag##_##mtag(tables[i]);      \
     fill_merged1_##tag##_##mtag(tables[i]);     \
@@ -126,7 +124,7 @@ kernel_fn pick_kernel(int dtype, int metric, int cfg, bool full) { return kernel
 kernel_fn pick_scan_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).scan[cfg][full]; }
 kernel_fn pick_sorted_kernel(int dtype, int metric, int cfg, bool full, int mode, int B) {  // mode: MODE_* below, != 0
   const KernelTable& t = kernel_table(dtype, metric);
-  return mode == 3 ? (B <= WAVE ? t.merged1[cfg][full] : t.merged[cfg][full]) : mode == 2 ? t.sorted_lds[cfg][full] : t.sorted_regs[cfg][full];
+  return mode == 3 ? (B <= WAVE ? t.merged1[cfg][full] : t.merged[cfg][full]) : t.sorted_lds[cfg][full];
 }
 wire_fn pick_wire_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).select[cfg][full]; }
 wire_fn pick_connect_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).connect[cfg][full]; }
@@ -174,8 +172,8 @@ struct fnv_index_s {
   // options
   int64_t visited_factor = 27, visited_slots = 0, visited_floor = 2048, occupancy_target = 13, cand_factor = 2,
           cand_slots = 0, spill_entries = 16384, blocks_per_cu = 0, visited_wide = 0,
-          entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0, register_beam = 2, sorted_beam = 2,
-          sorted_beam_min = 1, sorted_cand_lds = 2, sorted_tail_exact_pct = -1, merged_beam = 2;
+          entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0, sorted_beam = 2,
+          sorted_beam_min = 1, sorted_cand_lds = 2, sorted_tail_exact_pct = -1, merged_beam = 1;
   uint64_t options_version = 0;
   LaunchPlan plan;
   // adaptive kernel choice ("sorted_beam" = 2): per beam width, the best time per query seen for each variant
@@ -402,7 +400,7 @@ int fnv_index_view(fnv_index_t src, fnv_index_t* out) {
   v->occupancy_target = src->occupancy_target; v->cand_factor = src->cand_factor; v->cand_slots = src->cand_slots;
   v->spill_entries = src->spill_entries; v->blocks_per_cu = src->blocks_per_cu; v->visited_wide = src->visited_wide;
   v->entry_kernel = src->entry_kernel; v->output_node_ids = src->output_node_ids; v->visited_tag_bits = src->visited_tag_bits;
-  v->register_beam = src->register_beam; v->sorted_beam = src->sorted_beam; v->sorted_beam_min = src->sorted_beam_min;
+  v->sorted_beam = src->sorted_beam; v->sorted_beam_min = src->sorted_beam_min;
   v->sorted_cand_lds = src->sorted_cand_lds; v->overflow_list = src->overflow_list;
   v->sorted_tail_exact_pct = src->sorted_tail_exact_pct;
   v->merged_beam = src->merged_beam;
@@ -533,7 +531,6 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   else if (n == "entry_kernel") ix->entry_kernel = value;
   else if (n == "output_node_ids") ix->output_node_ids = value;
   else if (n == "overflow_list") ix->overflow_list = value;
-  else if (n == "register_beam") ix->register_beam = value;
   else if (n == "sorted_beam") ix->sorted_beam = value;
   else if (n == "sorted_beam_min") ix->sorted_beam_min = value;
   else if (n == "sorted_cand_lds") ix->sorted_cand_lds = value;
@@ -563,7 +560,7 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
 // ---- launch configuration ---------------------------------------------------------------------------------
 // How a query slot's LDS is laid out depends on the kernel: the two-heap kernel keeps {query, neighbours heap,
 // candidates heap, visited table, staging}; the sorted-beam kernels keep {query, [beam array], visited table, staging}.
-enum { MODE_HEAPS = 0, MODE_SORTED_REGS = 1, MODE_SORTED_LDS = 2, MODE_MERGED = 3 };
+enum { MODE_HEAPS = 0, MODE_SORTED_LDS = 2, MODE_MERGED = 3 };
 
 // Visited-table geometry for a table of `slots` (2^j or 3*2^j) and the LDS layout that follows from it; returns the
 // bytes of LDS one query slot needs.  16-bit tags whenever the per-bucket id range fits 14 bits: buckets =
@@ -731,17 +728,14 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     int rc = configure_launch(ix, plan.heaps, plan.kern, MODE_HEAPS, &plan.lds, &plan.bpc);
     if (rc) return rc;
 
-    // Sorted-beam kernel (sorted_beam.hpp): the beam as one sorted array, in registers for beams of at most 64
-    // entries ("register_beam" != 0), else in LDS; queries in which equal keys meet at a decision are searched
-    // again by the same wave with the exact two-heap code.  Same results.  "sorted_beam": 0 = never, 1 = always,
-    // 2 (default) = adaptive: used until more than a fifth of a launch's queries needed the exact search (integer
-    // data with wide beams ties everywhere), then the two-heap kernel serves that beam width on this index.
+    // Sorted-beam kernels: the beam as one sorted array -- in registers with one merge per link row for beams of at
+    // most 256 entries (merged_beam.hpp; "merged_beam" = 0 turns it off), else in LDS (sorted_beam.hpp); queries in
+    // which equal keys meet at a decision are searched again by the same wave with the exact two-heap code.  Same
+    // results.  "sorted_beam": 0 = never, 1 = always, 2 (default) = adaptive: measured against the two-heap kernel
+    // per beam width (below).
     const bool tagged = plan.heaps.vis_tag16 != 0;
     const bool want = ix->sorted_beam != 0 && B >= ix->sorted_beam_min && ix->capacity < (1ull << 31);
-    plan.mode = (!tagged || !want) ? MODE_HEAPS : (B <= WAVE && ix->register_beam != 0) ? MODE_SORTED_REGS : MODE_SORTED_LDS;
-    // "merged_beam": 1 = beams of 65...256 entries, 2 = every beam <= 256 -> the merged-beam kernel (merged_beam.hpp)
-    if (plan.mode != MODE_HEAPS && B <= fnv_dev::MB_MAX_BEAM && (ix->merged_beam >= 2 || (ix->merged_beam == 1 && B > WAVE)))
-      plan.mode = MODE_MERGED;
+    plan.mode = (!tagged || !want) ? MODE_HEAPS : (B <= fnv_dev::MB_MAX_BEAM && ix->merged_beam != 0) ? MODE_MERGED : MODE_SORTED_LDS;
     if (plan.mode != MODE_HEAPS) {
       plan.skern = pick_sorted_kernel(ix->dtype, ix->metric, cfg, full, plan.mode, B);
       // the exact re-run's candidates heap: in LDS if that costs neither resident queries nor visited-table

@@ -1,7 +1,7 @@
 // kernel_inst.hip -- one compilation = the instantiations of ONE kernel family for ONE (element type, metric):
 //   hipcc -c -DFNV_INST_T=float -DFNV_INST_TAG=f32 -DFNV_INST_METRIC=0 -DFNV_INST_MTAG=l2 -DFNV_INST_FAMILY=2 ...
-// families: 0 exact two-heap kernel + entry scan, 1 sorted beam in registers, 2 sorted beam in LDS, 3 wiring kernels,
-// 4 merged beam (<= 256 entries), 5 merged beam (<= 64 entries).  flatnav_amd/build.py compiles the 36 combinations in parallel and links them with beam_search.hip.
+// families: 0 exact two-heap kernel + entry scan, 2 sorted beam in LDS, 3 wiring kernels, 4 merged beam (<= 256
+// entries), 5 merged beam (<= 64 entries).  flatnav_amd/build.py compiles the 30 combinations in parallel and links them with beam_search.hip.
 #include <hip/hip_runtime.h>
 
 #include "kernel_table.h"
@@ -34,12 +34,8 @@ static void fill_rows(KernelTable& t) {
 #if FNV_INST_FAMILY == 0
   FNV_ROW(t.exact, beam_search_kernel)
   FNV_ROW(t.scan, entry_scan_kernel)
-#elif FNV_INST_FAMILY == 1
-#define FNV_COMMA_FALSE , false
-  FNV_ROW(t.sorted_regs, beam_search_sorted_kernel, FNV_COMMA_FALSE)
 #elif FNV_INST_FAMILY == 2
-#define FNV_COMMA_TRUE , true
-  FNV_ROW(t.sorted_lds, beam_search_sorted_kernel, FNV_COMMA_TRUE)
+  FNV_ROW(t.sorted_lds, beam_search_sorted_kernel)
 #elif FNV_INST_FAMILY == 4
 #define FNV_COMMA_MB_R , MB_R
   FNV_ROW(t.merged, beam_search_merged_kernel, FNV_COMMA_MB_R)
@@ -54,8 +50,6 @@ static void fill_rows(KernelTable& t) {
 
 #if FNV_INST_FAMILY == 0
 void FNV_CAT(fill_exact_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
-#elif FNV_INST_FAMILY == 1
-void FNV_CAT(fill_sorted_regs_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 #elif FNV_INST_FAMILY == 2
 void FNV_CAT(fill_sorted_lds_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 #elif FNV_INST_FAMILY == 4

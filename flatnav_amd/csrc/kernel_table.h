@@ -32,7 +32,6 @@ inline int pick_row_cfg(uint32_t nchunks) {
 struct KernelTable {
   kernel_fn exact[kNumCfgs][2];        // beam_search_kernel (two heaps, libstdc++-exact)
   kernel_fn scan[kNumCfgs][2];         // entry_scan_kernel (K0)
-  kernel_fn sorted_regs[kNumCfgs][2];  // beam_search_sorted_kernel, beam in registers
   kernel_fn sorted_lds[kNumCfgs][2];   // beam_search_sorted_kernel, beam in LDS
   kernel_fn merged[kNumCfgs][2];       // beam_search_merged_kernel (beam <= 256 in registers, one merge per link row)
   kernel_fn merged1[kNumCfgs][2];      // ... its one-chunk form (beam <= 64)
@@ -47,7 +46,6 @@ struct KernelTable {
 // one filler per kernel family and (type, metric), each defined by one compilation of kernel_inst.hip
 #define FNV_DECLARE_FILLERS(T, tag, M, mtag)             \
   void fill_exact_##tag##_##mtag(KernelTable& t);        \
-  void fill_sorted_regs_##tag##_##mtag(KernelTable& t);  \
   void fill_sorted_lds_##tag##_##mtag(KernelTable& t);   \
   void fill_merged_##tag##_##mtag(KernelTable& t);       \
   void fill_merged1_##tag##_##mtag(KernelTable& t);      \

@@ -3,12 +3,11 @@
 // beam_search_sorted_kernel: the same traversal as beam_search_kernel (the libstdc++-exact two-heap kernel) with the
 // beam held as ONE SORTED ARRAY of at most B entries -- closest first, an "expanded" flag per entry -- instead of the
 // reference's two binary heaps (neighbors: B+1 entries, candidates: every admitted node, 2B+192 slots here).
-//   WIDE = false   B <= 64: the array lives in registers, lane i = i-th closest entry (insertion = one wave shift);
-//   WIDE = true    any B:   the array lives in LDS, 8 bytes per entry {key | id, bit 31 = expanded}; an insertion
-//                  reads/writes only the 64-entry chunks above the insertion point.
-// The LDS form needs B*8 bytes where the heap kernel needs (3B+194)*8, which is what keeps 11-16 queries resident per
-// CU at beam widths of 400-1200 (the heap kernel: 3-5); an admission costs tens of instructions instead of three
-// cooperative heap operations (~250).
+// This kernel keeps the array in LDS, 8 bytes per entry {key | id, bit 31 = expanded}, for any beam width; an
+// insertion reads/writes only the 64-entry chunks above the insertion point.  It needs B*8 bytes where the heap
+// kernel needs (3B+194)*8, which is what keeps 11-16 queries resident per CU at beam widths of 400-1200 (the heap
+// kernel: 3-5).  Beams of at most 256 entries are served by merged_beam.hpp (the array in registers, one merge per
+// link row; same rules), which replaced this file's former register form (one wave shift per insertion).
 //
 // Why this is the same search.  The reference (Index.h:606-707) keeps `neighbors` (max-heap, <= B entries) and
 // `candidates` (every admitted node, min-first).  A candidate that has been evicted from `neighbors` has a key
@@ -37,24 +36,17 @@
 #include "kernels.hpp"
 namespace fnv_dev {
 
-__device__ __forceinline__ float wave_shr1(float v, float fill) {
-  // lane i <- lane i-1, lane 0 <- fill
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xF, 0xF, false));
-}
-__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t fill) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false);
-}
 __device__ __forceinline__ float readlane_f(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-constexpr uint32_t EXPANDED_BIT = 0x80000000u;  // WIDE entries: id in bits 0-30 (the host checks capacity < 2^31)
-constexpr int NO_ENTRY = 1 << 30;               // WIDE: "no unexpanded entry" (compares >= every beam size)
+constexpr uint32_t EXPANDED_BIT = 0x80000000u;  // beam entries: id in bits 0-30 (the host checks capacity < 2^31)
+constexpr int NO_ENTRY = 1 << 30;               // "no unexpanded entry" (compares >= every beam size)
 
 #ifndef FNV_SORTED_WAVES_PER_SIMD
 #define FNV_SORTED_WAVES_PER_SIMD 4
 #endif
-template <typename T, int METRIC, int G, int CU, bool FULL, bool WIDE>
+template <typename T, int METRIC, int G, int CU, bool FULL>
 __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_sorted_kernel(const SearchParams p) {
   constexpr int PU = passes<G, CU>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -74,14 +66,14 @@ __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_s
     const uint32_t* const links = ca->links;
     const uint32_t row_bytes = ca->row_bytes;
     const int nchunks = (int)ca->nchunks;
-    const int B = ca->B;  // WIDE = false: <= 64
+    const int B = ca->B;
     const int M = (int)ca->M;
     const VisGeom vg{ca->vis_nmask, ca->vis_rshift, ca->vis_rmask, ca->vis_mult, ca->vis_w};
     uint4* qlds = reinterpret_cast<uint4*>(smem + ca->off_q);
     uint32_t* vis = reinterpret_cast<uint32_t*>(smem + ca->off_vis);
     uint32_t* stage_ids = reinterpret_cast<uint32_t*>(smem + ca->off_stage_ids);
     uint32_t* ovf_list = reinterpret_cast<uint32_t*>(smem + ca->off_ovf);
-    // [B + 2] at 16n + 8: the sorted beam (WIDE; slot B = write-only bin), and the neighbours heap of an exact re-run
+    // [B + 2] at 16n + 8: the sorted beam (slot B = write-only bin), and the neighbours heap of an exact re-run
     unsigned long long* beam = reinterpret_cast<unsigned long long*>(smem + ca->off_nbr);
     stage_query<T>(qlds, vis, ovf_list, qi, true, lane);
     __syncthreads();
@@ -97,15 +89,11 @@ __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_s
     uint32_t* const ovf_glist = cold_args()->ovf_glist + (uint64_t)blockIdx.x * cold_args()->ovf_cap;
 
     // ---- the beam --------------------------------------------------------------------------------------------
-    // registers: lane i holds the i-th closest entry; lanes >= n hold +inf / junk that is never < a new key
-    float kr = lane == 0 ? best_d : INF;
-    uint32_t ir = lane == 0 ? entry : EMPTY_ID;
-    unsigned long long expanded = 0ull;  // registers: bit i = entry i has been expanded
-    int cur = 0;                         // LDS: index of the first unexpanded entry (>= n: none)
-    if (WIDE && lane == 0) beam[0] = pack(fnv_stl::Entry{best_d, entry});
+    int cur = 0;  // index of the first unexpanded entry (>= n: none)
+    if (lane == 0) beam[0] = pack(fnv_stl::Entry{best_d, entry});
     int n = 1;
     float max_dist = best_d;
-    float second = -INF;  // LDS, full beam: key of entry B-2 (the runner-up for eviction)
+    float second = -INF;  // full beam: key of entry B-2 (the runner-up for eviction)
     bool ovf = false;
     if (vg.w == 16) visited_insert_tag16(vis, vg, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
     else visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), vg, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
@@ -124,20 +112,7 @@ __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_s
       // ---- pick the closest unexpanded member; (b) its runner-up must not have the same key -------------------
       int node;
       float key_c;
-      if (!WIDE) {
-        const unsigned long long valid = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
-        const unsigned long long avail = ~expanded & valid;
-        if (avail == 0ull) break;  // every beam member expanded: what is left in the reference's queue is stale
-        const int c = __ffsll((long long)avail) - 1;
-        node = __builtin_amdgcn_readlane((int)ir, c);
-        key_c = readlane_f(kr, c);
-        const unsigned long long rest = avail & (avail - 1ull);
-        if (rest != 0ull) {
-          const int c2 = __ffsll((long long)rest) - 1;
-          if (readlane_f(kr, c2) == key_c) pend = fmaxf(pend, key_c);
-        }
-        expanded |= 1ull << c;
-      } else {
+      {
         if (cur >= n) break;
         // window of 64 entries starting at the first unexpanded one: lane 0 = the node to expand, the first other
         // unexpanded lane = the runner-up (the window slides on in the rare case that it holds none)
@@ -233,18 +208,7 @@ __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_s
               // choice, and the one it evicts stays expandable while max_dist equals its key.  Neither matters
               // unless the search gets that far: remember the key, hand the query over only if a node with a key
               // >= it is about to be expanded or the search ends before max_dist has dropped below it.
-              if (!WIDE) {
-                if (n >= B && B >= 2 && readlane_f(kr, B - 2) == max_dist) amb = max_dist;
-                const int pos = __popcll(__ballot(kr <= di));  // after the members that are not farther
-                const float sk = wave_shr1(kr, INF);
-                const uint32_t si = wave_shr1(ir, EMPTY_ID);
-                kr = lane > pos ? sk : (lane == pos ? di : kr);
-                ir = lane > pos ? si : (lane == pos ? idi : ir);
-                const unsigned long long low = (1ull << pos) - 1ull;
-                expanded = (expanded & low) | ((expanded & ~low) << 1);
-                if (n < B) n++;
-                max_dist = readlane_f(kr, n - 1);  // Index.h:702
-              } else {
+              {
                 if (n >= B && B >= 2 && second == max_dist) amb = max_dist;
                 // entries farther than di move one slot up, top chunk first; the first chunk that holds a member
                 // that is not farther fixes the position.  A full beam drops its last entry.
@@ -284,15 +248,10 @@ __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_s
     if (!tie && pend > -INF && n >= B && !(max_dist > pend)) tie = 2;  // (b) likewise
     const int cnt = n < K ? n : K;
     if (!tie) {  // (d) equal keys inside the first K results or across the K-th boundary: std::sort's order
-      if (!WIDE) {
-        const float nxt = __shfl_down(kr, 1, WAVE);
-        if (__ballot(lane < cnt && lane + 1 < n && nxt == kr) != 0ull) tie = 3;
-      } else {
-        for (int k0 = 0; k0 < cnt && !tie; k0 += WAVE) {
-          const int k = k0 + lane;
-          const bool t = k < cnt && k + 1 < n && unpack(beam[min(k, n - 1)]).key == unpack(beam[min(k + 1, n - 1)]).key;
-          if (__ballot(t) != 0ull) tie = 3;
-        }
+      for (int k0 = 0; k0 < cnt && !tie; k0 += WAVE) {
+        const int k = k0 + lane;
+        const bool t = k < cnt && k + 1 < n && unpack(beam[min(k, n - 1)]).key == unpack(beam[min(k + 1, n - 1)]).key;
+        if (__ballot(t) != 0ull) tie = 3;
       }
     }
     if (tie) {  // search this query again, exactly (results, counters and clean-up are exact_query's)
@@ -330,13 +289,9 @@ __global__ __launch_bounds__(WAVE, FNV_SORTED_WAVES_PER_SIMD) void beam_search_s
       int32_t* ol_base = c->out_labels + (uint64_t)qi * K;
       for (int k = lane; k < K; k += WAVE) {
         const bool have = k < cnt;
-        float od = kr;
-        uint32_t oi = ir;
-        if (WIDE) {
-          const fnv_stl::Entry e = unpack(beam[min(k, n - 1)]);
-          od = e.key;
-          oi = e.val & ~EXPANDED_BIT;
-        }
+        const fnv_stl::Entry e = unpack(beam[min(k, n - 1)]);
+        const float od = e.key;
+        const uint32_t oi = e.val & ~EXPANDED_BIT;
         od_base[k] = have ? od : INF;
         ol_base[k] = have ? (labels ? labels[oi] : (int32_t)oi) : -1;
       }

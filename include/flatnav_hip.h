@@ -154,9 +154,10 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *   "spill_entries"   per-slot HBM spill capacity of the candidate heap (default 16384)
  *   "blocks_per_cu"   cap resident query slots per CU (0 = occupancy limit)
  *   "output_node_ids" 1 = out_labels receives node ids, not labels (used by the device-assisted builder)
- *   "sorted_beam"     the sorted-beam kernel (csrc/sorted_beam.hpp: the beam as one sorted array instead of the
- *                     reference's two heaps; a query in which equal distances meet at a decision is searched again
- *                     by the same wavefront with the exact two-heap code, so results are the same either way):
+ *   "sorted_beam"     the sorted-beam kernels (the beam as one sorted array instead of the reference's two heaps --
+ *                     csrc/merged_beam.hpp for beams of at most 256 entries, csrc/sorted_beam.hpp beyond; a query in
+ *                     which equal distances meet at a decision is searched again by the same wavefront with the
+ *                     exact two-heap code, so results are the same either way):
  *                     0 = never (two-heap kernel only), 1 = always, 2 (default) = adaptive -- launches of >= 2048
  *                     queries are timed per beam width, first each variant twice, then the fastest serves that beam
  *                     width (which one wins depends on how often the data ties).  Needs capacity < 2^31 nodes.
@@ -164,16 +165,14 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *                     of a sorted-beam launch go straight to the exact search: a query that is searched twice
  *                     finishes late, and in the last round that lengthens the whole launch.  -1 (default) = one more
  *                     variant for the adaptive choice to measure (0 or 100); >= 0 = fixed
- *   "merged_beam"     the merged-beam kernel (csrc/merged_beam.hpp: the sorted beam held in registers for beams of up
- *                     to 256 entries, one merge per link row instead of one insertion per admitted neighbour; same
- *                     tie rules and exact re-run as the sorted-beam kernel, same results): 0 = never, 1 = beams of
- *                     65...256 entries, 2 (default) = every beam of at most 256 entries
+ *   "merged_beam"     != 0 (default): beams of at most 256 entries are served by the merged-beam kernel (the sorted
+ *                     beam held in registers, one merge per link row instead of one insertion per admitted
+ *                     neighbour); 0 = the LDS-array kernel of csrc/sorted_beam.hpp serves every beam width.  Same
+ *                     tie rules, same exact re-run, same results
  *   "sorted_beam_min" smallest beam width the sorted-beam kernel is used for (default 1)
  *   "sorted_cand_lds" where the exact re-run of the sorted-beam kernel keeps its candidates heap: 2 (default) = in LDS
  *                     when that costs neither resident queries nor visited-table slots, else in the slot's HBM spill
  *                     area; 0 = always HBM, 1 = always LDS (tests)
- *   "register_beam"   != 0 (default): beams of at most 64 entries keep the sorted array in registers, wider ones in
- *                     LDS; 0 = always in LDS
  *   "entry_kernel"    1 = entry points of the whole batch come from the LDS-staged entry_scan_kernel (K0);
  *                     0 (default) = every query scans them inside the search kernel.  Same results bit for
  *                     bit; measured equally fast on MI355X (the shared scan rows are L2 hits either way)
@@ -235,7 +234,7 @@ int fnv_last_replayed_queries(fnv_index_t index, uint64_t out[5]);
 
 /* Launch geometry of the most recent search: geom[8] = {grid_blocks, block_threads, lds_bytes,
  * blocks_per_cu, visited_slots, cand_slots (LDS entries of the exact search's candidates heap), kernel: 0 = two-heap
- * kernel, 1 = sorted beam in registers, 2 = sorted beam in LDS, 3 = merged beam, tail_exact: the last that-many queries of the launch
+ * kernel, 2 = sorted beam in LDS, 3 = merged beam (registers), tail_exact: the last that-many queries of the launch
  * went straight to the exact search (sorted-beam kernels, see the "sorted_tail_exact_pct" option)}. */
 int fnv_last_launch_geometry(fnv_index_t index, uint64_t geom[8]);
 

@@ -192,8 +192,8 @@ def test_wide_tag_visited_tables_stay_exact(oracle_mod, hipmod, dt):
 
 @pytest.mark.parametrize("case", ["u8_ties", "sift_f32", "randn_ip", "i8_ip"])
 def test_sorted_beam_kernel_stays_exact(oracle_mod, hipmod, case):
-    # Sorted-beam kernels (default): the beam as one sorted array -- in registers for beams <= 64, else in LDS -- or,
-    # merged-beam kernel, in registers for beams <= 256 with one merge per link row instead of one-by-one insertion.  A
+    # Sorted-beam kernels (default): the beam as one sorted array -- merged-beam kernel: in registers for beams <= 256,
+    # one merge per link row; beyond (or with "merged_beam" = 0): in LDS, one insertion per admitted neighbour.  A
     # query in which equal keys meet at a decision is searched again by the same wave with the exact two-heap code
     # (candidates heap in LDS or, when LDS is short, in the HBM spill area); ids, distances, counts and the per-query
     # counters must equal the two-heap kernel's and the oracle's bit for bit.
@@ -219,12 +219,9 @@ def test_sorted_beam_kernel_stays_exact(oracle_mod, hipmod, case):
             _assert_exact(ix.search(Q, K, ef, stats=True), want)
         dev.set_option("sorted_beam", 1)
         wide = max(K, ef) > 256  # the merged-beam kernel (beam in registers, one merge per link row) serves <= 256
-        forms = [(1, "sorted_beam_registers" if max(K, ef) <= 64 else "sorted_beam_lds", 2, 0), (0, "sorted_beam_lds", 2, 0),
-                 (0, "sorted_beam_lds", 0, 0), (1, None, 1, 0), (1, "sorted_beam_lds" if wide else "merged_beam", 2, 2),
-                 (0, "sorted_beam_lds" if wide else "merged_beam", 0, 2),
-                 (1, "merged_beam" if 64 < max(K, ef) <= 256 else None, 2, 1)]
-        for regs, kernel, cand_lds, merged in forms:
-            dev.set_option("register_beam", regs)
+        forms = [("sorted_beam_lds" if wide else "merged_beam", 2, 1), ("sorted_beam_lds" if wide else "merged_beam", 0, 1),
+                 (None, 1, 1), ("sorted_beam_lds", 2, 0), ("sorted_beam_lds", 0, 0)]
+        for kernel, cand_lds, merged in forms:
             dev.set_option("merged_beam", merged)
             dev.set_option("sorted_cand_lds", cand_lds)  # 0: the exact re-run keeps its candidates heap in HBM
             got = dev.search(Q, K, ef, stats=True)
@@ -239,8 +236,11 @@ def test_sorted_beam_kernel_stays_exact(oracle_mod, hipmod, case):
             if case == "randn_ip" and ef <= 200:
                 assert r["total"] <= len(Q) // 20
     dev.set_option("sorted_cand_lds", 2)
+    dev.set_option("merged_beam", 1)
     dev.set_option("visited_slots", 256)  # visited ids overflow into the HBM bitmap, in the first pass and the re-run
     _assert_exact(want, dev.search(Q, 10, 1000, stats=True))
+    _assert_exact(dev.search(Q, 10, 200, stats=True), (lambda: (dev.set_option("sorted_beam", 0), dev.search(Q, 10, 200, stats=True))[1])())
+    dev.set_option("sorted_beam", 1)
     dev.set_option("visited_slots", 0)
     # adaptive default: launches of >= 2048 queries are timed, both kernels get their samples, the faster one stays;
     # where (almost) every query ties that is the two-heap kernel.  Whatever runs, the bytes are the same.
@@ -278,7 +278,7 @@ def test_sorted_beam_tail_goes_straight_to_the_exact_search(oracle_mod, hipmod, 
             dev.set_option("sorted_tail_exact_pct", pct)
             got = dev.search(Q, 10, ef, stats=True)
             g = dev.launch_geometry()
-            assert g["kernel"] in ("sorted_beam_registers", "merged_beam") and g["grid_blocks"] < len(Q)
+            assert g["kernel"] == "merged_beam" and g["grid_blocks"] < len(Q)
             assert g["tail_exact"] == min(len(Q), pct * g["grid_blocks"] // 100)
             _assert_exact(want, got)
         # one round only: there is no tail

@@ -43,7 +43,7 @@ else:
     for ef in (32, 52, 64, 100, 200, 400, 800):
         modes = [("heaps", {"sorted_beam": 0})]
         for t in ((0, 50, 75, 100, 125, 150, 200) if ef <= 64 else (0, 12, 25, 50, 75)):
-            modes.append(("sorted t%d" % t, {"sorted_beam": 1, "register_beam": 1, "sorted_tail_exact_pct": t}))
+            modes.append(("sorted t%d" % t, {"sorted_beam": 1, "sorted_tail_exact_pct": t}))
         for mode, opts in modes:
             for k, v in opts.items(): dev.set_option(k, v)
             dev.search(Q, 10, ef)

@@ -21,7 +21,7 @@ def run(name, metric, dt, X, Q, efs):
         for ef in efs:
             res = {}
             for exact in (1, 0):
-                d.set_option("register_beam", 1 - exact)
+                d.set_option("sorted_beam", 1 - exact)
                 for _ in range(2): d.search_device(dq.data_ptr(), NQ, K, ef, 100, dd.data_ptr(), dl.data_ptr())
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 for _ in range(5): d.search_device(dq.data_ptr(), NQ, K, ef, 100, dd.data_ptr(), dl.data_ptr())
