@@ -406,8 +406,8 @@ def main() -> None:
                               "achieved_GBps": m2["achieved"], "mean_dist_evals_per_query": m2["nd"]})
     if rank == 0:
         kname = {"two_heaps": "fnv_dev::beam_search_kernel",
-                 "sorted_beam_lds": "fnv_dev::beam_search_sorted_kernel",
-                 "merged_beam": "fnv_dev::beam_search_merged_kernel"}[geom["kernel"]]
+                 "merged_beam_registers": "fnv_dev::beam_search_merged_kernel",
+                 "merged_beam_lds": "fnv_dev::beam_search_merged_kernel"}[geom["kernel"]]
         out = {
             "metric": "qps_at_recall10_ge_0.95",
             "value": main_m["qps"],

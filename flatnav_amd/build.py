@@ -18,13 +18,13 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libflatnav_hip.so")
 HEADERS = [os.path.join(CSRC, f) for f in ("search_params.h", "kernel_table.h", "heaps.hpp", "distance.hpp", "visited.hpp",
-                                           "kernels.hpp", "wire.hpp", "sorted_beam.hpp", "merged_beam.hpp", "relayout.hpp")] + [
+                                           "kernels.hpp", "wire.hpp", "merged_beam.hpp", "relayout.hpp")] + [
     os.path.join(ROOT, "include", "flatnav", "util", "StlExact.h"), os.path.join(ROOT, "include", "flatnav_hip.h")]
 MAIN = os.path.join(CSRC, "beam_search.hip")
 INST = os.path.join(CSRC, "kernel_inst.hip")
 TYPES = [("float", "f32"), ("uint8_t", "u8"), ("int8_t", "i8")]
 METRICS = [(0, "l2"), (1, "ip")]
-FAMILIES = [(0, "exact"), (2, "sorted_lds"), (3, "wire"), (4, "merged"), (5, "merged1")]
+FAMILIES = [(0, "exact"), (3, "wire"), (4, "merged"), (5, "merged1"), (6, "merged0")]
 
 
 def hipcc() -> str:

@@ -23,7 +23,7 @@
 //
 // Also here: incremental construction (fnv_index_write_nodes / write_links / insert_batch: Index::add,
 // include/flatnav/index/Index.h:353-378 with selectNeighbors :714-763 and connectNeighbors :765-834 as the
-// wire_select / wire_connect kernels of wire.hpp) and the sorted-beam kernels (sorted_beam.hpp).
+// wire_select / wire_connect kernels of wire.hpp) and the merged-beam search kernel (merged_beam.hpp).
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
@@ -42,7 +42,6 @@
 #include "kernel_table.h"
 #ifdef FNV_DEV_FAST_BUILD
 #include "kernels.hpp"
-#include "sorted_beam.hpp"
 #include "merged_beam.hpp"
 #endif
 #include "relayout.hpp"
@@ -88,9 +87,9 @@ const KernelTable& kernel_table(int, int) {
       for (int f = 0; f < 2; f++) {
         k.exact[c][f] = beam_search_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
         k.scan[c][f] = entry_scan_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
-        k.sorted_lds[c][f] = beam_search_sorted_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
         k.merged[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, MB_R>;
         k.merged1[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, 1>;
+        k.merged0[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, 0>;
         k.select[c][f] = wire_select_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
         k.connect[c][f] = wire_connect_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
       }
@@ -107,9 +106,9 @@ const KernelTable& kernel_table(int dtype, int metric) {
     int i = 0;
 #define FNV_FILL(T, tag, M, mtag)              \
     fill_exact_##tag##_##mtag(tables[i]);       \
-    fill_sorted_lds_##tag##_##mtag(tables[i]);  \
     fill_merged_##tag##_##mtag(tables[i]);      \
     fill_merged1_##tag##_##mtag(tables[i]);     \
+    fill_merged0_##tag##_##mtag(tables[i]);     \
     fill_wire_##tag##_##mtag(tables[i]);        \
     i++;
     FNV_FOR_EACH_TYPE_METRIC(FNV_FILL)
@@ -122,9 +121,9 @@ const KernelTable& kernel_table(int dtype, int metric) {
 
 kernel_fn pick_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).exact[cfg][full]; }
 kernel_fn pick_scan_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).scan[cfg][full]; }
-kernel_fn pick_sorted_kernel(int dtype, int metric, int cfg, bool full, int mode, int B) {  // mode: MODE_* below, != 0
+kernel_fn pick_sorted_kernel(int dtype, int metric, int cfg, bool full, bool lds, int B) {
   const KernelTable& t = kernel_table(dtype, metric);
-  return mode == 3 ? (B <= WAVE ? t.merged1[cfg][full] : t.merged[cfg][full]) : t.sorted_lds[cfg][full];
+  return lds ? t.merged0[cfg][full] : B <= WAVE ? t.merged1[cfg][full] : t.merged[cfg][full];
 }
 wire_fn pick_wire_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).select[cfg][full]; }
 wire_fn pick_connect_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).connect[cfg][full]; }
@@ -138,7 +137,7 @@ struct LaunchPlan {
   int B = 0, K = 0, cfg = 0, mode = 0;
   bool full = false;
   uint64_t capacity = 0, options_version = 0;
-  kernel_fn kern = nullptr, skern = nullptr;  // exact two-heap kernel; sorted-beam kernel (mode != 0)
+  kernel_fn kern = nullptr, skern = nullptr;  // exact two-heap kernel; merged-beam kernel (mode != 0)
   SearchParams heaps, sorted;                 // geometry + LDS layout for each (per-call fields unset)
   uint32_t lds = 0, slds = 0;
   int bpc = 0, sbpc = 0;
@@ -173,12 +172,12 @@ struct fnv_index_s {
   int64_t visited_factor = 27, visited_slots = 0, visited_floor = 2048, occupancy_target = 13, cand_factor = 2,
           cand_slots = 0, spill_entries = 16384, blocks_per_cu = 0, visited_wide = 0,
           entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0, sorted_beam = 2,
-          sorted_beam_min = 1, sorted_cand_lds = 2, sorted_tail_exact_pct = -1, merged_beam = 1;
+          sorted_beam_min = 1, sorted_cand_lds = 2, sorted_tail_exact_pct = -1, beam_registers = 1;
   uint64_t options_version = 0;
   LaunchPlan plan;
   // adaptive kernel choice ("sorted_beam" = 2): per beam width, the best time per query seen for each variant
   struct Tuner {
-    // ms per query: [0] two-heap kernel, [1] sorted-beam kernel, [2] sorted-beam kernel whose last round of queries
+    // ms per query: [0] two-heap kernel, [1] merged-beam kernel, [2] merged-beam kernel whose last round of queries
     // goes straight to the exact search ("sorted_tail_exact_pct" = 100; only launches of more than one round)
     float best[3] = {-1.f, -1.f, -1.f};
     int samples[3] = {0, 0, 0};
@@ -188,7 +187,7 @@ struct fnv_index_s {
   uint64_t sample_nq = 0;
   int64_t overflow_list = -1;  // -1: automatic (a list in HBM only when the bitmap is larger than 512 KB)
   // workspace (grown on demand)
-  uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status, [3] queries a sorted-beam launch searched exactly, [4..7] by reason
+  uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status, [3] queries a merged-beam launch searched exactly, [4..7] by reason
   unsigned long long* d_phase = nullptr;  // profiling builds only
   void* d_entry = nullptr;  // [nq] uint32 entry nodes | [nq] float entry distances (K0 output)
   size_t entry_bytes = 0;
@@ -403,7 +402,7 @@ int fnv_index_view(fnv_index_t src, fnv_index_t* out) {
   v->sorted_beam = src->sorted_beam; v->sorted_beam_min = src->sorted_beam_min;
   v->sorted_cand_lds = src->sorted_cand_lds; v->overflow_list = src->overflow_list;
   v->sorted_tail_exact_pct = src->sorted_tail_exact_pct;
-  v->merged_beam = src->merged_beam;
+  v->beam_registers = src->beam_registers;
   if (hipSetDevice(v->device) != hipSuccess) {
     delete v;
     return fail(FNV_ERR_NO_DEVICE, "hipSetDevice failed");
@@ -535,7 +534,7 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   else if (n == "sorted_beam_min") ix->sorted_beam_min = value;
   else if (n == "sorted_cand_lds") ix->sorted_cand_lds = value;
   else if (n == "sorted_tail_exact_pct") ix->sorted_tail_exact_pct = value;
-  else if (n == "merged_beam") ix->merged_beam = value;
+  else if (n == "beam_registers") ix->beam_registers = value;
   else if (n == "visited_tag_bits") ix->visited_tag_bits = value;
   else return fail(FNV_ERR_INVALID, "unknown option: " + n);
   ix->options_version++;
@@ -559,8 +558,8 @@ int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, 
 
 // ---- launch configuration ---------------------------------------------------------------------------------
 // How a query slot's LDS is laid out depends on the kernel: the two-heap kernel keeps {query, neighbours heap,
-// candidates heap, visited table, staging}; the sorted-beam kernels keep {query, [beam array], visited table, staging}.
-enum { MODE_HEAPS = 0, MODE_SORTED_LDS = 2, MODE_MERGED = 3 };
+// candidates heap, visited table, staging}; the merged-beam kernel keeps {query, [beam array], visited table, staging}.
+enum { MODE_HEAPS = 0, MODE_MERGED_REGS = 1, MODE_MERGED_LDS = 2 };
 
 // Visited-table geometry for a table of `slots` (2^j or 3*2^j) and the LDS layout that follows from it; returns the
 // bytes of LDS one query slot needs.  16-bit tags whenever the per-bucket id range fits 14 bits: buckets =
@@ -598,8 +597,12 @@ static uint32_t lay_out(const fnv_index_s* ix, SearchParams& p, uint32_t slots, 
   // neighbours heap (exact search) / sorted beam: arrays start at 16n + 8 so that child pairs are 16-byte aligned
   p.off_nbr = off + 8;
   // (merged-beam kernel: the same bytes stage a link row's distances, [WAVE + 1] floats, between two merges)
-  off = align16(off + 8 + std::max<uint32_t>(((uint32_t)p.B + 2) * 8, mode == MODE_MERGED ? (WAVE + 1) * 4 : 0));
+  off = align16(off + 8 + std::max<uint32_t>(((uint32_t)p.B + 2) * 8, mode == MODE_MERGED_REGS ? (WAVE + 1) * 4 : 0));
   p.off_stage_d = p.off_nbr;
+  if (mode == MODE_MERGED_LDS) {  // LDS form: the array is the beam itself, the staging area its own
+    p.off_stage_d = off;
+    off = align16(off + (WAVE + 1) * 4);
+  }
   p.off_cand = off + 8;  // candidates heap of the exact search: cand_slots entries in LDS (0: all of it in HBM)
   if (p.cand_slots) off = align16(off + 8 + (p.cand_slots + 1) * 8);
   p.off_vis = off;
@@ -722,22 +725,21 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     plan.cfg = cfg;
     plan.full = full;
 
-    // the exact two-heap kernel: always configured (it also replays what a sorted-beam kernel hands over)
+    // the exact two-heap kernel: always configured (it also replays what a merged-beam kernel hands over)
     plan.heaps = p;
     plan.kern = pick_kernel(ix->dtype, ix->metric, cfg, full);
     int rc = configure_launch(ix, plan.heaps, plan.kern, MODE_HEAPS, &plan.lds, &plan.bpc);
     if (rc) return rc;
 
-    // Sorted-beam kernels: the beam as one sorted array -- in registers with one merge per link row for beams of at
-    // most 256 entries (merged_beam.hpp; "merged_beam" = 0 turns it off), else in LDS (sorted_beam.hpp); queries in
-    // which equal keys meet at a decision are searched again by the same wave with the exact two-heap code.  Same
-    // results.  "sorted_beam": 0 = never, 1 = always, 2 (default) = adaptive: measured against the two-heap kernel
-    // per beam width (below).
+    // Merged-beam kernel (merged_beam.hpp): the beam as one sorted array, one merge per link row -- in registers for
+    // beams of at most 256 entries ("beam_registers" = 0: never), else in LDS; queries in which equal keys meet at a
+    // decision are searched again by the same wave with the exact two-heap code.  Same results.  "sorted_beam":
+    // 0 = never, 1 = always, 2 (default) = adaptive: measured against the two-heap kernel per beam width (below).
     const bool tagged = plan.heaps.vis_tag16 != 0;
     const bool want = ix->sorted_beam != 0 && B >= ix->sorted_beam_min && ix->capacity < (1ull << 31);
-    plan.mode = (!tagged || !want) ? MODE_HEAPS : (B <= fnv_dev::MB_MAX_BEAM && ix->merged_beam != 0) ? MODE_MERGED : MODE_SORTED_LDS;
+    plan.mode = (!tagged || !want) ? MODE_HEAPS : (B <= MB_MAX_BEAM && ix->beam_registers != 0) ? MODE_MERGED_REGS : MODE_MERGED_LDS;
     if (plan.mode != MODE_HEAPS) {
-      plan.skern = pick_sorted_kernel(ix->dtype, ix->metric, cfg, full, plan.mode, B);
+      plan.skern = pick_sorted_kernel(ix->dtype, ix->metric, cfg, full, plan.mode == MODE_MERGED_LDS, B);
       // the exact re-run's candidates heap: in LDS if that costs neither resident queries nor visited-table
       // slots, else entirely in the slot's HBM spill area (slower for the few queries that need it)
       SearchParams with = p, without = p;
@@ -762,13 +764,13 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     plan.valid = true;
   }
   // Adaptive choice ("sorted_beam" = 2): both kernels give the same answers; which one is faster depends on how often
-  // equal keys force the sorted-beam kernel to search a query twice (rarely on float data, often on integer-valued
+  // equal keys force the merged-beam kernel to search a query twice (rarely on float data, often on integer-valued
   // data with wide beams) -- so it is measured: launches of at least 2048 queries are timed by the events that bracket
   // them anyway, harvested when a later call finds them complete, first one kernel, then the other, then the faster.
   bool sorted = plan.mode != MODE_HEAPS;
   bool sample = false;
   int variant = sorted ? 1 : 0;
-  // The sorted-beam kernel's stragglers: a query that is searched twice finishes a whole exact-search latency late, and
+  // The merged-beam kernel's stragglers: a query that is searched twice finishes a whole exact-search latency late, and
   // in the last round of a launch that lengthens the launch itself (one such query costs as much as hundreds).  With
   // "sorted_tail_exact_pct" = p the last p % of one round of queries skip the sorted pass (the exact search is slower but
   // never needs a second one): -15 % on the integer-valued SIFT stand-in at ef=52, +0-4 % on float data without ties --

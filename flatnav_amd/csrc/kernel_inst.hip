@@ -1,12 +1,11 @@
 // kernel_inst.hip -- one compilation = the instantiations of ONE kernel family for ONE (element type, metric):
-//   hipcc -c -DFNV_INST_T=float -DFNV_INST_TAG=f32 -DFNV_INST_METRIC=0 -DFNV_INST_MTAG=l2 -DFNV_INST_FAMILY=2 ...
-// families: 0 exact two-heap kernel + entry scan, 2 sorted beam in LDS, 3 wiring kernels, 4 merged beam (<= 256
-// entries), 5 merged beam (<= 64 entries).  flatnav_amd/build.py compiles the 30 combinations in parallel and links them with beam_search.hip.
+//   hipcc -c -DFNV_INST_T=float -DFNV_INST_TAG=f32 -DFNV_INST_METRIC=0 -DFNV_INST_MTAG=l2 -DFNV_INST_FAMILY=4 ...
+// families: 0 exact two-heap kernel + entry scan, 3 wiring kernels, 4 merged beam (<= 256 entries in registers),
+// 5 merged beam (<= 64 entries in registers), 6 merged beam (LDS, any width).  flatnav_amd/build.py compiles the 30 combinations in parallel and links them with beam_search.hip.
 #include <hip/hip_runtime.h>
 
 #include "kernel_table.h"
 #include "kernels.hpp"
-#include "sorted_beam.hpp"
 #include "merged_beam.hpp"
 #include "wire.hpp"
 
@@ -34,14 +33,15 @@ static void fill_rows(KernelTable& t) {
 #if FNV_INST_FAMILY == 0
   FNV_ROW(t.exact, beam_search_kernel)
   FNV_ROW(t.scan, entry_scan_kernel)
-#elif FNV_INST_FAMILY == 2
-  FNV_ROW(t.sorted_lds, beam_search_sorted_kernel)
 #elif FNV_INST_FAMILY == 4
 #define FNV_COMMA_MB_R , MB_R
   FNV_ROW(t.merged, beam_search_merged_kernel, FNV_COMMA_MB_R)
 #elif FNV_INST_FAMILY == 5
 #define FNV_COMMA_ONE , 1
   FNV_ROW(t.merged1, beam_search_merged_kernel, FNV_COMMA_ONE)
+#elif FNV_INST_FAMILY == 6
+#define FNV_COMMA_ZERO , 0
+  FNV_ROW(t.merged0, beam_search_merged_kernel, FNV_COMMA_ZERO)
 #else
   FNV_ROW(t.select, wire_select_kernel)
   FNV_ROW(t.connect, wire_connect_kernel)
@@ -50,12 +50,12 @@ static void fill_rows(KernelTable& t) {
 
 #if FNV_INST_FAMILY == 0
 void FNV_CAT(fill_exact_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
-#elif FNV_INST_FAMILY == 2
-void FNV_CAT(fill_sorted_lds_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 #elif FNV_INST_FAMILY == 4
 void FNV_CAT(fill_merged_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 #elif FNV_INST_FAMILY == 5
 void FNV_CAT(fill_merged1_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
+#elif FNV_INST_FAMILY == 6
+void FNV_CAT(fill_merged0_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 #else
 void FNV_CAT(fill_wire_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 #endif

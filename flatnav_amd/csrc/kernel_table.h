@@ -32,9 +32,9 @@ inline int pick_row_cfg(uint32_t nchunks) {
 struct KernelTable {
   kernel_fn exact[kNumCfgs][2];        // beam_search_kernel (two heaps, libstdc++-exact)
   kernel_fn scan[kNumCfgs][2];         // entry_scan_kernel (K0)
-  kernel_fn sorted_lds[kNumCfgs][2];   // beam_search_sorted_kernel, beam in LDS
   kernel_fn merged[kNumCfgs][2];       // beam_search_merged_kernel (beam <= 256 in registers, one merge per link row)
   kernel_fn merged1[kNumCfgs][2];      // ... its one-chunk form (beam <= 64)
+  kernel_fn merged0[kNumCfgs][2];      // ... its LDS form (any beam width)
   wire_fn select[kNumCfgs][2];         // wire_select_kernel
   wire_fn connect[kNumCfgs][2];        // wire_connect_kernel
 };
@@ -46,9 +46,9 @@ struct KernelTable {
 // one filler per kernel family and (type, metric), each defined by one compilation of kernel_inst.hip
 #define FNV_DECLARE_FILLERS(T, tag, M, mtag)             \
   void fill_exact_##tag##_##mtag(KernelTable& t);        \
-  void fill_sorted_lds_##tag##_##mtag(KernelTable& t);   \
   void fill_merged_##tag##_##mtag(KernelTable& t);       \
   void fill_merged1_##tag##_##mtag(KernelTable& t);      \
+  void fill_merged0_##tag##_##mtag(KernelTable& t);      \
   void fill_wire_##tag##_##mtag(KernelTable& t);
 FNV_FOR_EACH_TYPE_METRIC(FNV_DECLARE_FILLERS)
 #undef FNV_DECLARE_FILLERS

@@ -176,7 +176,7 @@ __device__ __forceinline__ uint32_t entry_point(const uint8_t* vectors, uint32_t
 // ---------------------------------------------------------------------------------------------
 // The exact search of ONE query (Index.h:606-707 + :393-408): the reference's two binary heaps moved with
 // libstdc++'s element moves, link-order admissions, result tail.  Called by beam_search_kernel for every query
-// and by beam_search_sorted_kernel for the queries in which equal keys met at a decision.
+// and by beam_search_merged_kernel for the queries in which equal keys met at a decision.
 // Expects the query staged in qlds, the visited table reset, entry / best_d chosen.
 // ---------------------------------------------------------------------------------------------
 struct ExactCtx {

@@ -1,33 +1,74 @@
 // merged_beam.hpp -- part of the gfx950 search engine (device code; included only by beam_search.hip / kernel_inst.hip).
 //
-// beam_search_merged_kernel: the sorted-beam search (sorted_beam.hpp: same traversal as the reference's two heaps,
-// same tie rules, same in-wave exact re-run) for beams of up to R * 64 entries (instantiated for R = 4 and R = 1), with
-//   * the beam RESIDENT IN REGISTERS: entry e lives in lane e % 64 of register pair (kr, ir)[e / 64], closest first;
-//     bit 31 of the id word is the "expanded" flag, entries beyond the beam's size hold {+inf, EMPTY_ID} (whose bit
-//     31 is set, so they never look unexpanded);
-//   * ONE MERGE PER LINK ROW instead of one insertion per admitted neighbour: the row's distances are staged in LDS,
-//     lane j takes the j-th evaluated neighbour (link order), and every element of beam U candidates computes its
-//     position in the stable merge (beam entries before candidates of equal key, candidates in link order -- the
-//     arrangement the one-by-one insertions of sorted_beam.hpp produce) from wave ballots:
-//         beam entry e      -> e + #{candidates with a smaller key}
-//         candidate j       -> #{beam keys <= d_j} + #{candidates before j in (key, link order)}
-//     The permutation itself goes through the LDS beam array (one scatter, one read back of the chunks that moved).
+// beam_search_merged_kernel -- the default search kernel: the same traversal as beam_search_kernel (the libstdc++-exact
+// two-heap kernel) with the beam held as ONE SORTED ARRAY of at most B entries -- closest first, an "expanded" flag
+// per entry (bit 31 of the id word) -- instead of the reference's two binary heaps (neighbors: B+1 entries,
+// candidates: every admitted node, 2B+192 slots in the heap kernel), and ONE MERGE PER LINK ROW instead of one
+// insertion per admitted neighbour.  Template parameter R:
+//   R = 4, 1   beams of up to R * 64 entries RESIDENT IN REGISTERS: entry e lives in lane e % 64 of register pair
+//              (kr, ir)[e / 64]; entries beyond the beam's size hold {+inf, EMPTY_ID} (whose bit 31 is set, so they
+//              never look unexpanded).  The merge's permutation goes through the LDS array (one scatter, one read
+//              back of the chunks that moved).
+//   R = 0      any beam width: the array stays in LDS (8 bytes per entry -- where the heap kernel needs (3B+194)*8,
+//              which is what keeps 11-16 queries resident per CU at beam widths of 400-1200; the heap kernel: 3-5)
+//              and is merged IN PLACE, 64-entry chunks from the top down, until a full chunk none of whose
+//              entries moves.
 //
-// Why the merge is the reference's admission loop (Index.h:693-704).  Taken one by one in link order, a neighbour is
+// Why this is the same search.  The reference (Index.h:606-707) keeps `neighbors` (max-heap, <= B entries) and
+// `candidates` (every admitted node, min-first).  A candidate that has been evicted from `neighbors` has a key
+// >= max_dist and max_dist never grows once the beam is full, so when such a candidate reaches the top of
+// `candidates` the stop test (Index.h:630) fires; it is never expanded.  The nodes that do get
+// expanded are therefore exactly the not-yet-expanded members of `neighbors`, closest first -- which is what
+// "first entry whose expanded flag is clear" picks here.
+//
+// The merge is the reference's admission loop (Index.h:693-704).  Taken one by one in link order, a neighbour is
 // admitted iff the beam is not full or d < max_dist, and a full beam then drops its farthest member.  An element
 // among the B smallest of beam U row is never dropped (when it is the farthest of a full beam and something closer
 // arrives, B elements are closer than it) and never refused; an element outside is refused or dropped by the end of
-// the row -- so the beam after the row is the B smallest of the union, whatever the order, PROVIDED no two keys are
-// equal where that cut falls.  Equal keys above the cut change nothing that lasts (both are gone by the end of the
-// row; nothing is expanded in between).  Equal keys AT the cut (an element left outside has the key of the new
-// farthest member) are sorted_beam.hpp's case (a): which one the reference keeps is the library's choice, and the
-// one it drops stays expandable while max_dist equals its key -- so `amb` is set to that key and the query is handed
-// to the exact search only if the search gets that far (same deferred rule; this kernel flags a refused candidate
-// with d == max_dist as well, which the reference decides by its strict '<' -- conservative, never wrong).
-// A NaN / infinite distance that could be admitted hands the query over at once.
+// the row -- so the beam after the row is the B smallest of the union, whatever the order.  The row's distances are
+// staged in LDS, lane j takes the j-th evaluated neighbour (link order), and every element computes its position in
+// the stable merge (beam entries before candidates of equal key, candidates in link order) from wave ballots:
+//         beam entry e      -> e + #{candidates with a smaller key}
+//         candidate j       -> #{beam keys <= d_j} + #{candidates before j in (key, link order)}
+//
+// The ARRANGEMENT of the reference's heaps (libstdc++'s element moves) only decides something when equal keys meet at
+// a decision:
+//   (a) eviction: equal keys where the cut falls -- an element left outside the new beam has the key of the new
+//       farthest member.  Which one the reference keeps is the library's choice, and the one it drops stays expandable
+//       while max_dist equals its key.  Neither matters unless the search gets that far: `amb` remembers the key, the
+//       query is handed over only if a node with a key >= it is about to be expanded or the search ends before
+//       max_dist has dropped below it.  (A refused candidate with d == max_dist is flagged as well, which the reference
+//       decides by its strict '<' -- conservative, never wrong.  Equal keys ABOVE the cut change nothing that lasts:
+//       both are gone by the end of the row and nothing is expanded in between.)
+//   (b) selection: the two closest unexpanded members have equal keys k (which one is expanded first).  Harmless if
+//       every evaluated node with a key <= k is still in the beam when the search moves past k (max_dist > k, or the
+//       beam is not full): then, whichever order the reference takes, each node with a key <= k has fewer than B
+//       better nodes at its turn, so all of them get expanded, the same links get evaluated, and beam, visited set
+//       and expanded set are the same once the last of them is done.  The check is therefore deferred (`pend`);
+//   (d) result: equal keys among the first K results or across the K-th boundary (std::sort's order).
+// Equal keys elsewhere in the beam decide nothing.  Each of the three spots is checked where it arises; a query
+// that hits one, or meets a NaN / infinite distance that could be admitted, is abandoned and searched again -- by the
+// same wave, right away -- with exact_query(), the libstdc++-exact two-heap search (its neighbours heap takes over the
+// LDS array; its candidates heap lives in LDS when that costs no residency, else in the slot's HBM spill area).
+// Otherwise results, their order and the per-query counters are identical by construction; the parity tests
+// compare them bit for bit, tie-heavy inputs included.  History (profiles/r2_sorted_beam.md): a separate replay launch
+// was tried first (one whole query latency at almost no parallelism, 0.5-0.7 ms on a 1.3 ms launch); the first
+// in-kernel versions inserted admitted neighbours one by one (a wave shift in registers / a chunk walk in LDS per
+// insertion) -- the merge costs a third of the instructions at four admissions per row.
 #pragma once
-#include "sorted_beam.hpp"
+#include "kernels.hpp"
 namespace fnv_dev {
+
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+constexpr uint32_t EXPANDED_BIT = 0x80000000u;  // beam entries: id in bits 0-30 (the host checks capacity < 2^31)
+constexpr int NO_ENTRY = 1 << 30;               // LDS form: "no unexpanded entry" (compares >= every beam size)
+
+#ifndef FNV_SORTED_WAVES_PER_SIMD
+#define FNV_SORTED_WAVES_PER_SIMD 4
+#endif
 
 // order-preserving map float -> uint32 (no NaNs, -0 canonicalised by the caller)
 __device__ __forceinline__ uint32_t float_ord(float f) {
@@ -70,7 +111,11 @@ __global__ __launch_bounds__(WAVE, (CU == 1 && R == 1) ? 5 : FNV_SORTED_WAVES_PE
     const int qi = next_query(lane);
     if (qi < 0) break;
     PH_DECL
-    ColdArgs ca = cold_args();  // per-query constants: see sorted_beam.hpp
+    // Per-query constants are re-read from the kernel arguments at the top of every query (a dozen scalar loads) and
+    // again by the exact re-run below: nothing but the loop itself is then live across the two code paths, so the
+    // register allocation of this loop does not pay for the heaps' (inlined together without this, the loop lost
+    // 11 % to scalar-register spills).
+    ColdArgs ca = cold_args();
     const uint8_t* const vectors = ca->vectors;
     const uint32_t* const links = ca->links;
     const uint32_t row_bytes = ca->row_bytes;
@@ -98,17 +143,20 @@ __global__ __launch_bounds__(WAVE, (CU == 1 && R == 1) ? 5 : FNV_SORTED_WAVES_PE
     uint32_t* const bitmap = cold_args()->ovf_bitmap + (uint64_t)blockIdx.x * cold_args()->bitmap_words;
     uint32_t* const ovf_glist = cold_args()->ovf_glist + (uint64_t)blockIdx.x * cold_args()->ovf_cap;
 
-    float kr[R];
-    uint32_t ir[R];
+    constexpr int RR = R > 0 ? R : 1;
+    float kr[RR];    // register form (R > 0)
+    uint32_t ir[RR];
 #pragma unroll
-    for (int r = 0; r < R; r++) {
+    for (int r = 0; r < RR; r++) {
       kr[r] = INF;
       ir[r] = EMPTY_ID;
     }
     if (lane == 0) {
       kr[0] = best_d;
       ir[0] = entry;
+      if (R == 0) beam[0] = pack(fnv_stl::Entry{best_d, entry});
     }
+    int cur = 0;  // LDS form (R == 0): index of the first unexpanded entry (>= n: none)
     int n = 1;
     float max_dist = best_d;
     bool ovf = false;
@@ -124,27 +172,54 @@ __global__ __launch_bounds__(WAVE, (CU == 1 && R == 1) ? 5 : FNV_SORTED_WAVES_PE
 
     while (!tie) {
       // ---- pick the closest unexpanded member; (b) its runner-up must not have the same key -------------------
-      int r1 = -1, l1 = 0, r2 = -1, l2 = 0;  // closest unexpanded member (chunk, lane) and its runner-up
+      int node;
+      float key_c;
+      if constexpr (R > 0) {
+        int r1 = -1, l1 = 0, r2 = -1, l2 = 0;  // closest unexpanded member (chunk, lane) and its runner-up
 #pragma unroll
-      for (int r = 0; r < R; r++) {
-        unsigned long long u = __ballot((int32_t)ir[r] >= 0);  // entries beyond the beam hold EMPTY_ID: bit 31 set
-        if (r1 < 0 && u != 0ull) {
-          r1 = r;
-          l1 = __ffsll((long long)u) - 1;
-          u &= u - 1ull;
+        for (int r = 0; r < R; r++) {
+          unsigned long long u = __ballot((int32_t)ir[r] >= 0);  // entries beyond the beam hold EMPTY_ID: bit 31 set
+          if (r1 < 0 && u != 0ull) {
+            r1 = r;
+            l1 = __ffsll((long long)u) - 1;
+            u &= u - 1ull;
+          }
+          if (r1 >= 0 && r2 < 0 && u != 0ull) {
+            r2 = r;
+            l2 = __ffsll((long long)u) - 1;
+          }
         }
-        if (r1 >= 0 && r2 < 0 && u != 0ull) {
-          r2 = r;
-          l2 = __ffsll((long long)u) - 1;
+        if (r1 < 0) break;  // every beam member expanded: what is left in the reference's queue is stale
+        node = lane_of(ir, r1, l1);
+        key_c = lane_of(kr, r1, l1);
+        if (r2 >= 0 && lane_of(kr, r2, l2) == key_c) pend = fmaxf(pend, key_c);
+#pragma unroll
+        for (int r = 0; r < R; r++)
+          if (r == r1) ir[r] |= lane == l1 ? EXPANDED_BIT : 0u;
+      } else {
+        if (cur >= n) break;
+        // window of 64 entries starting at the first unexpanded one: lane 0 = the node to expand, the first other
+        // unexpanded lane = the runner-up (the window slides on in the rare case that it holds none)
+        const int c0 = cur;
+        fnv_stl::Entry w = unpack(beam[min(c0 + lane, n - 1)]);
+        node = __builtin_amdgcn_readlane((int)w.val, 0);
+        key_c = readlane_f(w.key, 0);
+        int c2 = NO_ENTRY;
+        for (int base = c0;;) {
+          const unsigned long long un = __ballot(base + lane < n && !(w.val & EXPANDED_BIT) && base + lane > c0);
+          if (un) {
+            const int l2 = __ffsll((long long)un) - 1;
+            c2 = base + l2;
+            if (readlane_f(w.key, l2) == key_c) pend = fmaxf(pend, key_c);
+            break;
+          }
+          base += WAVE;
+          if (base >= n) break;
+          w = unpack(beam[min(base + lane, n - 1)]);
         }
+        if (lane == 0) beam[c0] = pack(fnv_stl::Entry{key_c, (uint32_t)node | EXPANDED_BIT});
+        cur = c2;
       }
-      if (r1 < 0) break;  // every beam member expanded: what is left in the reference's queue is stale
-      const int node = lane_of(ir, r1, l1);
-      const float key_c = lane_of(kr, r1, l1);
-      if (r2 >= 0 && lane_of(kr, r2, l2) == key_c) pend = fmaxf(pend, key_c);
-#pragma unroll
-      for (int r = 0; r < R; r++)
-        if (r == r1) ir[r] |= lane == l1 ? EXPANDED_BIT : 0u;
       if (key_c >= amb) {  // (a) became relevant
         tie = 1;
         break;
@@ -213,71 +288,130 @@ __global__ __launch_bounds__(WAVE, (CU == 1 && R == 1) ? 5 : FNV_SORTED_WAVES_PE
           const unsigned long long key64 = ((unsigned long long)float_ord(d) << 32) | (uint32_t)lane;
           uint32_t rank = 0;   // candidate lane: candidates that precede it in (key, link order)
           int bpos = 0;        // candidate lane: beam keys <= its key
-          uint32_t le[R];      // beam lane: candidates whose key is >= the entry's key (they go after it)
+          const int n_new = min(B, n + c);
+          bool out_eq = false;  // this lane holds an element left outside the new beam, (smallest) key out_key
+          float out_key = INF;
+          if constexpr (R > 0) {
+            uint32_t le[R];  // beam lane: candidates whose key is >= the entry's key (they go after it)
 #pragma unroll
-          for (int r = 0; r < R; r++) le[r] = 0u;
-          for (unsigned long long mm = pm; mm != 0ull; mm &= mm - 1ull) {
-            const int i = __ffsll((long long)mm) - 1;
-            const float di = readlane_f(d, i);
-            const unsigned long long ki =
-                ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(key64 >> 32), i) << 32) | (uint32_t)i;
-            rank += ki < key64 ? 1u : 0u;
-            int cnt = 0;
+            for (int r = 0; r < R; r++) le[r] = 0u;
+            for (unsigned long long mm = pm; mm != 0ull; mm &= mm - 1ull) {
+              const int i = __ffsll((long long)mm) - 1;
+              const float di = readlane_f(d, i);
+              const unsigned long long ki =
+                  ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(key64 >> 32), i) << 32) | (uint32_t)i;
+              rank += ki < key64 ? 1u : 0u;
+              int cnt = 0;
+#pragma unroll
+              for (int r = 0; r < R; r++) {
+                if (r * WAVE < n) {  // wave-uniform
+                  const bool b = kr[r] <= di;  // entries beyond n hold +inf
+                  cnt += __popcll(__ballot(b));
+                  le[r] += b ? 1u : 0u;
+                }
+              }
+              bpos = lane == i ? cnt : bpos;
+            }
+            const int fpos = bpos + (int)rank;  // candidate's position in the stable merge
+            // scatter through LDS; a full chunk none of whose entries moves keeps its registers (the candidates all
+            // land above it)
+            bool moved[R];
 #pragma unroll
             for (int r = 0; r < R; r++) {
-              if (r * WAVE < n) {  // wave-uniform
-                const bool b = kr[r] <= di;  // entries beyond n hold +inf
-                cnt += __popcll(__ballot(b));
-                le[r] += b ? 1u : 0u;
-              }
-            }
-            bpos = lane == i ? cnt : bpos;
-          }
-          const int fpos = bpos + (int)rank;  // candidate's position in the stable merge
-          const int n_new = min(B, n + c);
-          bool out_eq = false;    // this lane's element is left outside the new beam (checked against the new max below)
-          float out_key = 0.f;
-          // scatter through LDS; a full chunk none of whose entries moves keeps its registers (the candidates all
-          // land above it)
-          bool moved[R];
-#pragma unroll
-          for (int r = 0; r < R; r++) {
-            moved[r] = false;
-            if (r * WAVE < n_new) {
-              const int e = r * WAVE + lane;
-              const int np = e + c - (int)le[r];
-              const bool valid = e < n;
-              moved[r] = (r + 1) * WAVE > n || __ballot(valid && (int)le[r] != c) != 0ull;
-              if (moved[r]) {
-                const bool keep = valid && np < B;
-                beam[keep ? np : -1] = pack(fnv_stl::Entry{kr[r], ir[r]});
-                if (valid && !keep) {
-                  out_eq = true;
-                  out_key = kr[r];
+              moved[r] = false;
+              if (r * WAVE < n_new) {
+                const int e = r * WAVE + lane;
+                const int np = e + c - (int)le[r];
+                const bool valid = e < n;
+                moved[r] = (r + 1) * WAVE > n || __ballot(valid && (int)le[r] != c) != 0ull;
+                if (moved[r]) {
+                  const bool keep = valid && np < B;
+                  beam[keep ? np : -1] = pack(fnv_stl::Entry{kr[r], ir[r]});
+                  if (valid && !keep) {
+                    out_eq = true;
+                    out_key = fminf(out_key, kr[r]);
+                  }
                 }
               }
             }
-          }
-          {
-            const bool keep = pass && fpos < B;
-            beam[keep ? fpos : -1] = pack(fnv_stl::Entry{d, cand_id});
-            if (pass && !keep) {
-              out_eq = true;
-              out_key = d;
+            {
+              const bool keep = pass && fpos < B;
+              beam[keep ? fpos : -1] = pack(fnv_stl::Entry{d, cand_id});
+              if (pass && !keep) {
+                out_eq = true;
+                out_key = fminf(out_key, d);
+              }
             }
-          }
-          wave_sync();
+            wave_sync();
 #pragma unroll
-          for (int r = 0; r < R; r++) {
-            if (moved[r]) {
-              const int idx = r * WAVE + lane;
-              const fnv_stl::Entry e = unpack(beam[idx < n_new ? idx : -1]);
-              kr[r] = idx < n_new ? e.key : INF;
-              ir[r] = idx < n_new ? e.val : EMPTY_ID;
+            for (int r = 0; r < R; r++) {
+              if (moved[r]) {
+                const int idx = r * WAVE + lane;
+                const fnv_stl::Entry e = unpack(beam[idx < n_new ? idx : -1]);
+                kr[r] = idx < n_new ? e.key : INF;
+                ir[r] = idx < n_new ? e.val : EMPTY_ID;
+              }
             }
+            n = rfl(n_new);
+            max_dist = lane_of(kr, (n - 1) >> 6, (n - 1) & (WAVE - 1));  // Index.h:702
+          } else {
+            // LDS form: the array is merged in place, 64-entry chunks from the top down -- an entry only ever moves
+            // up, by at most c slots, into space the chunks above have already left; a full chunk none of whose
+            // entries moves ends the walk (everything below is closer than every candidate as well)
+            for (unsigned long long mm = pm; mm != 0ull; mm &= mm - 1ull) {
+              const int i = __ffsll((long long)mm) - 1;
+              const unsigned long long ki =
+                  ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(key64 >> 32), i) << 32) | (uint32_t)i;
+              rank += ki < key64 ? 1u : 0u;
+            }
+            int shift_cur = 0;  // how far the first unexpanded entry moves
+            for (int r = (n - 1) >> 6; r >= 0; r--) {
+              const int e = r * WAVE + lane;
+              const bool valid = e < n;
+              const unsigned long long raw = beam[valid ? e : n - 1];
+              const float key = valid ? unpack(raw).key : INF;
+              int le = 0, cntv = 0;
+              for (unsigned long long mm = pm; mm != 0ull; mm &= mm - 1ull) {
+                const int i = __ffsll((long long)mm) - 1;
+                const bool b = key <= readlane_f(d, i);
+                le += b ? 1 : 0;
+                const int cnt = __popcll(__ballot(b));
+                cntv = lane == i ? cnt : cntv;
+              }
+              bpos += cntv;
+              if ((r + 1) * WAVE <= n && __ballot(valid && le != c) == 0ull) {
+                bpos += r * WAVE;  // the chunks below: every entry is <= every candidate
+                break;
+              }
+              const int np = e + c - le;
+              const bool keep = valid && np < B;
+              beam[keep ? np : -1] = raw;
+              if (valid && !keep) {
+                out_eq = true;
+                out_key = fminf(out_key, key);
+              }
+              if ((cur >> 6) == r && cur < n) shift_cur = c - __builtin_amdgcn_readlane(le, cur & (WAVE - 1));
+            }
+            const int fpos = bpos + (int)rank;
+            {
+              const bool keep = pass && fpos < B;
+              beam[keep ? fpos : -1] = pack(fnv_stl::Entry{d, cand_id});
+              if (pass && !keep) {
+                out_eq = true;
+                out_key = fminf(out_key, d);
+              }
+            }
+            wave_sync();
+            // first unexpanded entry: the old one where it went (gone if pushed out), or the closest candidate
+            int cur_new = cur < n ? cur + shift_cur : NO_ENTRY;
+            if (cur_new >= B) cur_new = NO_ENTRY;
+            const unsigned long long firstc = __ballot(pass && rank == 0u);  // exactly one candidate lane
+            const int fmin = __builtin_amdgcn_readlane(fpos, __ffsll((long long)firstc) - 1);
+            if (fmin < B) cur_new = min(cur_new, fmin);
+            cur = cur_new;
+            n = rfl(n_new);
+            max_dist = rfl(unpack(beam[n - 1]).key);  // Index.h:702
           }
-          n = rfl(n_new);
-          max_dist = lane_of(kr, (n - 1) >> 6, (n - 1) & (WAVE - 1));  // Index.h:702
           // (a) an element left outside has the key of the new farthest member
           if (__ballot(out_eq && out_key == max_dist) != 0ull) amb = max_dist;
           if (max_dist < amb) amb = INF;  // every entry with that key is gone from both versions of the beam
@@ -293,7 +427,14 @@ __global__ __launch_bounds__(WAVE, (CU == 1 && R == 1) ? 5 : FNV_SORTED_WAVES_PE
     if (!tie && amb < INF) tie = 1;  // (a) still undecided when the search ended
     if (!tie && pend > -INF && n >= B && !(max_dist > pend)) tie = 2;  // (b) likewise
     const int cnt = n < K ? n : K;
-    if (!tie) {  // (d) equal keys inside the first K results or across the K-th boundary: std::sort's order
+    if (!tie && R == 0) {  // (d), LDS form
+      for (int k0 = 0; k0 < cnt && !tie; k0 += WAVE) {
+        const int k = k0 + lane;
+        const bool t = k < cnt && k + 1 < n && unpack(beam[min(k, n - 1)]).key == unpack(beam[min(k + 1, n - 1)]).key;
+        if (__ballot(t) != 0ull) tie = 3;
+      }
+    }
+    if (!tie && R > 0) {  // (d) equal keys inside the first K results or across the K-th boundary: std::sort's order
 #pragma unroll
       for (int r = 0; r < R; r++) {
         if (r * WAVE < cnt) {
@@ -349,6 +490,15 @@ __global__ __launch_bounds__(WAVE, (CU == 1 && R == 1) ? 5 : FNV_SORTED_WAVES_PE
           const bool have = k < cnt;
           const uint32_t oi = ir[r] & ~EXPANDED_BIT;
           od_base[k] = have ? kr[r] : INF;
+          ol_base[k] = have ? (labels ? labels[oi] : (int32_t)oi) : -1;
+        }
+      }
+      if (R == 0) {
+        for (int k = lane; k < K; k += WAVE) {
+          const bool have = k < cnt;
+          const fnv_stl::Entry e = unpack(beam[min(k, n - 1)]);
+          const uint32_t oi = e.val & ~EXPANDED_BIT;
+          od_base[k] = have ? e.key : INF;
           ol_base[k] = have ? (labels ? labels[oi] : (int32_t)oi) : -1;
         }
       }

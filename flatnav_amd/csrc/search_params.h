@@ -46,7 +46,7 @@ struct SearchParams {
   uint64_t* out_ndist;      // [nq] or null
   uint64_t* out_nhops;      // [nq] or null
   uint32_t* dispenser;      // next query id
-  uint32_t* redo_count;     // sorted-beam kernel: [0] queries it searched again exactly (equal keys at a decision),
+  uint32_t* redo_count;     // merged-beam kernel: [0] queries it searched again exactly (equal keys at a decision),
                             // [1..4] by reason
   int32_t* status;          // sticky error flag for the whole launch
   uint32_t* ovf_bitmap;     // [nslots][bitmap_words] visited-set spill (all zero between queries)
@@ -73,7 +73,7 @@ struct SearchParams {
   uint32_t off_q, off_nbr, off_cand, off_vis, off_stage_ids;
   uint32_t off_stage_d;     // LDS: [WAVE + 1] distances of a link row's unvisited neighbours (merged-beam kernel; = off_nbr:
                             // the permutation buffer is idle while they are staged)
-  uint32_t tail_exact;     // sorted-beam kernel: the last tail_exact queries of the launch skip the sorted pass
+  uint32_t tail_exact;     // merged-beam kernel: the last tail_exact queries of the launch skip the sorted pass
 };
 
 // Broadcast of lane 0's value into a scalar register ("this value is wave-uniform").

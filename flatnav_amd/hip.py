@@ -276,6 +276,6 @@ class DeviceIndex:
         check(lib().fnv_last_launch_geometry(self._h, g))
         keys = ["grid_blocks", "block_threads", "lds_bytes", "blocks_per_cu", "visited_slots", "cand_slots"]
         out = {k: int(g[i]) for i, k in enumerate(keys)}
-        out["kernel"] = ["two_heaps", None, "sorted_beam_lds", "merged_beam"][int(g[6])]
+        out["kernel"] = ["two_heaps", "merged_beam_registers", "merged_beam_lds"][int(g[6])]
         out["tail_exact"] = int(g[7])
         return out

@@ -154,23 +154,21 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *   "spill_entries"   per-slot HBM spill capacity of the candidate heap (default 16384)
  *   "blocks_per_cu"   cap resident query slots per CU (0 = occupancy limit)
  *   "output_node_ids" 1 = out_labels receives node ids, not labels (used by the device-assisted builder)
- *   "sorted_beam"     the sorted-beam kernels (the beam as one sorted array instead of the reference's two heaps --
- *                     csrc/merged_beam.hpp for beams of at most 256 entries, csrc/sorted_beam.hpp beyond; a query in
- *                     which equal distances meet at a decision is searched again by the same wavefront with the
- *                     exact two-heap code, so results are the same either way):
+ *   "sorted_beam"     the merged-beam kernel (csrc/merged_beam.hpp: the beam as one sorted array instead of the
+ *                     reference's two heaps, one merge per link row; a query in which equal distances meet at a
+ *                     decision is searched again by the same wavefront with the exact two-heap code, so results are
+ *                     the same either way):
  *                     0 = never (two-heap kernel only), 1 = always, 2 (default) = adaptive -- launches of >= 2048
  *                     queries are timed per beam width, first each variant twice, then the fastest serves that beam
  *                     width (which one wins depends on how often the data ties).  Needs capacity < 2^31 nodes.
  *   "sorted_tail_exact_pct"  the last p % of one round of queries (one round = as many queries as stay resident)
- *                     of a sorted-beam launch go straight to the exact search: a query that is searched twice
+ *                     of a merged-beam launch go straight to the exact search: a query that is searched twice
  *                     finishes late, and in the last round that lengthens the whole launch.  -1 (default) = one more
  *                     variant for the adaptive choice to measure (0 or 100); >= 0 = fixed
- *   "merged_beam"     != 0 (default): beams of at most 256 entries are served by the merged-beam kernel (the sorted
- *                     beam held in registers, one merge per link row instead of one insertion per admitted
- *                     neighbour); 0 = the LDS-array kernel of csrc/sorted_beam.hpp serves every beam width.  Same
- *                     tie rules, same exact re-run, same results
- *   "sorted_beam_min" smallest beam width the sorted-beam kernel is used for (default 1)
- *   "sorted_cand_lds" where the exact re-run of the sorted-beam kernel keeps its candidates heap: 2 (default) = in LDS
+ *   "beam_registers"  != 0 (default): beams of at most 256 entries keep the sorted array in registers (the merge's
+ *                     permutation goes through LDS); 0 = the array always lives in LDS, as it does for wider beams
+ *   "sorted_beam_min" smallest beam width the merged-beam kernel is used for (default 1)
+ *   "sorted_cand_lds" where the exact re-run of the merged-beam kernel keeps its candidates heap: 2 (default) = in LDS
  *                     when that costs neither resident queries nor visited-table slots, else in the slot's HBM spill
  *                     area; 0 = always HBM, 1 = always LDS (tests)
  *   "entry_kernel"    1 = entry points of the whole batch come from the LDS-staged entry_scan_kernel (K0);
@@ -227,15 +225,15 @@ int fnv_search_status(fnv_index_t index);
  * fnv_search_batch[_device] call on this index; synchronises with that launch. */
 int fnv_last_kernel_ms(fnv_index_t index, float* ms);
 
-/* The sorted-beam kernel searches a query again with the exact (libstdc++-replay) two-heap code when equal
+/* The merged-beam kernel searches a query again with the exact (libstdc++-replay) two-heap code when equal
  * distances meet at a decision.  out[5] = queries of the most recent search that were: {total, eviction tie,
  * selection tie, result tie, NaN/inf}; synchronises with that launch.  Results do not depend on it. */
 int fnv_last_replayed_queries(fnv_index_t index, uint64_t out[5]);
 
 /* Launch geometry of the most recent search: geom[8] = {grid_blocks, block_threads, lds_bytes,
  * blocks_per_cu, visited_slots, cand_slots (LDS entries of the exact search's candidates heap), kernel: 0 = two-heap
- * kernel, 2 = sorted beam in LDS, 3 = merged beam (registers), tail_exact: the last that-many queries of the launch
- * went straight to the exact search (sorted-beam kernels, see the "sorted_tail_exact_pct" option)}. */
+ * kernel, 1 = merged-beam kernel with the beam in registers, 2 = with the beam in LDS, tail_exact: the last that-many queries of the launch
+ * went straight to the exact search (merged-beam kernel, see the "sorted_tail_exact_pct" option)}. */
 int fnv_last_launch_geometry(fnv_index_t index, uint64_t geom[8]);
 
 #ifdef __cplusplus

@@ -71,7 +71,7 @@ def test_c3_shape_768d_float_inner_product_ef200(oracle_mod, hipmod, kind):
     dev.set_option("sorted_beam", 2)
     dev.search(Q, 10, 200)
     g = dev.launch_geometry()
-    assert g["kernel"] == "merged_beam"  # what C3 runs on by default
+    assert g["kernel"] == "merged_beam_registers"  # what C3 runs on by default
     if kind == "lowrank_unit":
         gt = ds.exact_topk_ip(X, Q, 10)
         _, gl = dev.search(Q, 10, 200)

@@ -144,12 +144,12 @@ def test_spill_paths_stay_exact(oracle_mod, hipmod):
     o = ix.search(Q, 10, 100, stats=True)
     dev = _upload(hipmod, ix)
     dev.set_option("visited_slots", 256)  # 16-bit-tag table, 64 buckets: most ids end up in the bitmap
-    dev.set_option("sorted_beam", 1)  # sorted-beam kernel, exact re-run of the queries with ties
+    dev.set_option("sorted_beam", 1)  # merged-beam kernel, exact re-run of the queries with ties
     _assert_exact(o, dev.search(Q, 10, 100, stats=True))
-    assert dev.launch_geometry()["kernel"] == "merged_beam"
-    dev.set_option("merged_beam", 0)
+    assert dev.launch_geometry()["kernel"] == "merged_beam_registers"
+    dev.set_option("beam_registers", 0)
     _assert_exact(o, dev.search(Q, 10, 100, stats=True))
-    assert dev.launch_geometry()["kernel"] == "sorted_beam_lds"
+    assert dev.launch_geometry()["kernel"] == "merged_beam_lds"
     dev.set_option("sorted_beam", 0)  # from here on the two-heap kernel alone: its spill paths are the subject
     _assert_exact(o, dev.search(Q, 10, 100, stats=True))
     assert dev.launch_geometry()["kernel"] == "two_heaps"
@@ -192,8 +192,8 @@ def test_wide_tag_visited_tables_stay_exact(oracle_mod, hipmod, dt):
 
 @pytest.mark.parametrize("case", ["u8_ties", "sift_f32", "randn_ip", "i8_ip"])
 def test_sorted_beam_kernel_stays_exact(oracle_mod, hipmod, case):
-    # Sorted-beam kernels (default): the beam as one sorted array -- merged-beam kernel: in registers for beams <= 256,
-    # one merge per link row; beyond (or with "merged_beam" = 0): in LDS, one insertion per admitted neighbour.  A
+    # Merged-beam kernel (default): the beam as one sorted array, one merge per link row -- in registers for beams of
+    # at most 256 entries (one- and four-chunk forms), beyond that (or with "beam_registers" = 0) in LDS.  A
     # query in which equal keys meet at a decision is searched again by the same wave with the exact two-heap code
     # (candidates heap in LDS or, when LDS is short, in the HBM spill area); ids, distances, counts and the per-query
     # counters must equal the two-heap kernel's and the oracle's bit for bit.
@@ -218,11 +218,10 @@ def test_sorted_beam_kernel_stays_exact(oracle_mod, hipmod, case):
         if case != "randn_ip":
             _assert_exact(ix.search(Q, K, ef, stats=True), want)
         dev.set_option("sorted_beam", 1)
-        wide = max(K, ef) > 256  # the merged-beam kernel (beam in registers, one merge per link row) serves <= 256
-        forms = [("sorted_beam_lds" if wide else "merged_beam", 2, 1), ("sorted_beam_lds" if wide else "merged_beam", 0, 1),
-                 (None, 1, 1), ("sorted_beam_lds", 2, 0), ("sorted_beam_lds", 0, 0)]
-        for kernel, cand_lds, merged in forms:
-            dev.set_option("merged_beam", merged)
+        auto = "merged_beam_registers" if max(K, ef) <= 256 else "merged_beam_lds"
+        forms = [(auto, 2, 1), (auto, 0, 1), (None, 1, 1), ("merged_beam_lds", 2, 0), ("merged_beam_lds", 0, 0)]
+        for kernel, cand_lds, regs in forms:
+            dev.set_option("beam_registers", regs)
             dev.set_option("sorted_cand_lds", cand_lds)  # 0: the exact re-run keeps its candidates heap in HBM
             got = dev.search(Q, K, ef, stats=True)
             g = dev.launch_geometry()
@@ -236,7 +235,7 @@ def test_sorted_beam_kernel_stays_exact(oracle_mod, hipmod, case):
             if case == "randn_ip" and ef <= 200:
                 assert r["total"] <= len(Q) // 20
     dev.set_option("sorted_cand_lds", 2)
-    dev.set_option("merged_beam", 1)
+    dev.set_option("beam_registers", 1)
     dev.set_option("visited_slots", 256)  # visited ids overflow into the HBM bitmap, in the first pass and the re-run
     _assert_exact(want, dev.search(Q, 10, 1000, stats=True))
     _assert_exact(dev.search(Q, 10, 200, stats=True), (lambda: (dev.set_option("sorted_beam", 0), dev.search(Q, 10, 200, stats=True))[1])())
@@ -254,7 +253,7 @@ def test_sorted_beam_kernel_stays_exact(oracle_mod, hipmod, case):
         if first is None:
             first = got
         _assert_exact(first, got)
-    assert kernels[0] == "merged_beam" and "two_heaps" in kernels
+    assert kernels[0] == "merged_beam_registers" and "two_heaps" in kernels
     if case == "u8_ties":
         assert kernels[-1] == "two_heaps"
 
@@ -278,7 +277,7 @@ def test_sorted_beam_tail_goes_straight_to_the_exact_search(oracle_mod, hipmod, 
             dev.set_option("sorted_tail_exact_pct", pct)
             got = dev.search(Q, 10, ef, stats=True)
             g = dev.launch_geometry()
-            assert g["kernel"] == "merged_beam" and g["grid_blocks"] < len(Q)
+            assert g["kernel"] == "merged_beam_registers" and g["grid_blocks"] < len(Q)
             assert g["tail_exact"] == min(len(Q), pct * g["grid_blocks"] // 100)
             _assert_exact(want, got)
         # one round only: there is no tail

@@ -13,7 +13,7 @@ ix = flatnav.index.create("l2", 128, N, 32)
 ix.set_num_threads(8)
 ix.add(X, 100, device=True)
 dev = hip.DeviceIndex(ctypes.c_void_p(ix.device_handle()), owned=False)
-for kv in sys.argv[2:]:  # library options, e.g. merged_beam=2
+for kv in sys.argv[2:]:  # library options, e.g. beam_registers=0
     k, v = kv.split("="); dev.set_option(k, int(v))
 for ef in (50, 100, 200):
     for q in Q[:50]:
