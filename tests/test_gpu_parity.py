@@ -295,6 +295,25 @@ def test_sorted_beam_tail_goes_straight_to_the_exact_search(oracle_mod, hipmod, 
         assert {(True, False), (False, False), (False, True)} <= seen
 
 
+def test_infinite_distances_go_to_the_exact_search(oracle_mod, hipmod):
+    # Some rows lie so far out that their squared distance overflows float32 to +inf.  The merged-beam kernel does not
+    # reason about non-finite keys: a query that could admit one is handed to the exact two-heap search, which treats
+    # +inf like the reference does (an ordinary key that is never "< max_dist" once the beam is full).
+    rng = np.random.default_rng(21)
+    X, Q = ds.sift_like(6000, 300)
+    far = rng.choice(len(X), 300, replace=False)
+    X = X.copy(); X[far, rng.integers(0, 128, 300)] = 3e19
+    ix = _build(oracle_mod, "l2", "float32", X, 16)
+    dev = _upload(hipmod, ix)
+    for ef in (8, 64, 300):
+        want = ix.search(Q, 10, ef, stats=True)
+        for mode in (1, 0):
+            dev.set_option("sorted_beam", mode)
+            _assert_exact(want, dev.search(Q, 10, ef, stats=True))
+            if mode == 1 and ef == 8:
+                assert dev.replayed_queries()["nan_inf"] > 0  # small beams fill up with whatever comes first
+
+
 def test_labels_and_duplicate_links(oracle_mod, hipmod):
     rng = np.random.default_rng(5)
     X = rng.integers(0, 256, (3000, 64)).astype(np.float32)

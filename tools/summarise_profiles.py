@@ -40,18 +40,18 @@ def bench_launches(d, out_name, steps=20):
     return sum(dur) / len(dur) / 1e6
 
 
-def counters(d):
-    """Per-launch averages of the dominant search kernel's full-size launches."""
+def counters(d, steps=3):
+    """Per-launch averages over the profiled command's timed region: its last `steps` full-grid search launches (the
+    index construction and the ef sweep launch search kernels too -- other instantiations, or the same one earlier)."""
     rows = [r for r in csv.DictReader(open(find(d, "counter_collection.csv"))) if "beam_search" in r["Kernel_Name"]]
-    big = max(int(r["Grid_Size"]) for r in rows)
-    rows = [r for r in rows if int(r["Grid_Size"]) == big]
-    by_kernel = collections.Counter(r["Kernel_Name"] for r in rows)
-    kernel = by_kernel.most_common(1)[0][0]
+    ids = sorted({int(r["Dispatch_Id"]) for r in rows})[-steps:]  # the timed steps are the command's last launches
+    rows = [r for r in rows if int(r["Dispatch_Id"]) in ids]
+    kernel = rows[-1]["Kernel_Name"]
+    assert all(r["Kernel_Name"] == kernel for r in rows), "timed region mixes kernels"
     acc = collections.defaultdict(list)
     for r in rows:
-        if r["Kernel_Name"] == kernel:
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    first = next(r for r in rows if r["Kernel_Name"] == kernel)
+        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    first = rows[0]
     meta = {k: first[k] for k in ("Grid_Size", "Workgroup_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Kernel_Name")}
     return {k: sum(v) / len(v) for k, v in acc.items()}, meta
 
@@ -76,6 +76,22 @@ for dt in ("float32", "uint8"):
     })
     c, m = counters("sq_" + dt)
     sq[dt] = {"kernel": m, "per_launch": c}
+try:  # the wide-beam pass (config c4 at ef=400)
+    wb = json.load(open(os.path.join(O, "bench_c4_ef400.json")))
+    f, meta = counters("fetch_c4wide")
+    w, _ = counters("write_c4wide")
+    F, W = f["FETCH_SIZE"], w["WRITE_SIZE"]
+    alg = wb["roofline"]["achieved"] * 1e9 * wb["roofline"]["avg_kernel_ms"] / 1e3
+    traffic.append({"config": "c4", "dtype": "float32", "n": wb["config"].get("n"), "nq": 10000, "ef": 400, "kernel": meta,
+                    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --config c4 --no-cpu-baseline "
+                               "--no-secondary --sustain-seconds 0 --ef 400 --steps 3 --warmup 3",
+                    "FETCH_SIZE_KB_per_launch": F, "WRITE_SIZE_KB_per_launch": W,
+                    "hbm_bytes_per_launch_uncorrected": (F + W) * 1024, "hbm_bytes_per_launch_corrected": (2 * F + W) * 1024,
+                    "algorithmic_bytes_per_launch": alg,
+                    "note": "400-byte rows straddle four 128-byte lines (x1.28 of the algorithmic row bytes); the write side and the rest "
+                            "of the excess is the visited set's per-slot HBM bitmap (ids beyond the LDS table: read-modify-write of one line each)"})
+except (OSError, KeyError, SystemExit) as e:
+    print("no wide-beam pass:", e)
 json.dump([t for t in traffic if t["dtype"] == "float32"] + [t for t in traffic if t["dtype"] != "float32"],
           open(os.path.join(P, "%s_pmc_hbm_traffic.json" % tag), "w"), indent=1)
 json.dump({"ef": bench["config"]["ef_search"], "counters": sq}, open(os.path.join(P, "%s_sq_counters.json" % tag), "w"), indent=1)
