@@ -266,7 +266,7 @@ class DeviceIndex:
         return float(ms.value)
 
     def replayed_queries(self) -> dict:
-        """Queries of the last search that the exact kernel replayed after the register-beam kernel, by reason."""
+        """Queries of the last search that the exact kernel replayed after the merged-beam kernel handed them over, by reason."""
         r = (C.c_uint64 * 5)()
         check(lib().fnv_last_replayed_queries(self._h, r))
         return dict(zip(["total", "eviction_tie", "selection_tie", "result_tie", "nan_inf"], [int(x) for x in r]))
