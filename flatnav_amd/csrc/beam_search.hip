@@ -792,15 +792,15 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     if (nq >= 2048) {
       fnv_index_s::Tuner& t = ix->tuner[2 * B + (multi_round ? 1 : 0)];
       const bool try_tail = multi_round && ix->sorted_tail_exact_pct < 0;
-      // two samples each (the first launch of a kernel is a cold one), then the fastest
-      if (t.samples[1] < 2) variant = 1;
-      else if (t.samples[0] < 2) variant = 0;
-      else if (try_tail && t.samples[2] < 2) variant = 2;
+      // three samples each (the first launch of a kernel is a cold one; the best of the rest decides), then the fastest
+      if (t.samples[1] < 3) variant = 1;
+      else if (t.samples[0] < 3) variant = 0;
+      else if (try_tail && t.samples[2] < 3) variant = 2;
       else {
         variant = t.best[1] <= t.best[0] ? 1 : 0;
         if (try_tail && t.best[2] < t.best[variant]) variant = 2;
       }
-      sample = t.samples[variant] < 3;
+      sample = t.samples[variant] < 4;
       sorted = variant != 0;
       if (variant == 2) tail_pct = 100;
     }

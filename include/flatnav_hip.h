@@ -159,7 +159,7 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *                     decision is searched again by the same wavefront with the exact two-heap code, so results are
  *                     the same either way):
  *                     0 = never (two-heap kernel only), 1 = always, 2 (default) = adaptive -- launches of >= 2048
- *                     queries are timed per beam width, first each variant twice, then the fastest serves that beam
+ *                     queries are timed per beam width, first each variant three times, then the fastest serves that beam
  *                     width (which one wins depends on how often the data ties).  Needs capacity < 2^31 nodes.
  *   "sorted_tail_exact_pct"  the last p % of one round of queries (one round = as many queries as stay resident)
  *                     of a merged-beam launch go straight to the exact search: a query that is searched twice
