@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -203,6 +204,7 @@ class Index {
   // several GPUs: the mirror on _device_ordinal is the primary; replicas of it live on the other devices of
   // _device_list (filled by peer copies, refreshed whenever the primary changes); batches are sharded over all of them
   mutable std::vector<int> _device_list;   // empty: not decided yet (FLATNAV_DEVICES, else every visible GPU)
+  mutable bool _device_list_defaulted = false;  // "every visible GPU" was assumed, not asked for
   mutable std::vector<fnv_index_t> _replicas;
   mutable bool _replicas_stale = true;
 
@@ -448,6 +450,7 @@ class Index {
       _device_list.push_back(_device_ordinal);
       for (int d = 0; d < count; ++d)
         if (d != _device_ordinal) _device_list.push_back(d);
+      _device_list_defaulted = true;
     }
     const_cast<Index*>(this)->_device_ordinal = _device_list[0];
   }
@@ -463,6 +466,13 @@ class Index {
       const int rc = fnv_replicate(_device_index, static_cast<int>(_replicas.size()), _device_list.data() + 1, _replicas.data());
       if (rc != FNV_OK) {
         _replicas.clear();
+        if (_device_list_defaulted) {  // nobody asked for the other GPUs: serve from the primary alone, say so once
+          std::fprintf(stderr, "flatnav: replicating the index over %zu visible GPUs failed (%s); searching on device %d only\n",
+                       _device_list.size(), fnv_last_error(), _device_ordinal);
+          _device_list.assign(1, _device_ordinal);
+          _replicas_stale = false;
+          return;
+        }
         detail::throwOnDeviceError(rc);
       }
     } else {
@@ -512,6 +522,7 @@ class Index {
   void setDevices(const std::vector<int>& ordinals) {
     if (ordinals.empty()) throw std::invalid_argument("setDevices: at least one device ordinal is required");
     std::lock_guard<std::mutex> g(_device_guard);
+    _device_list_defaulted = false;
     if (ordinals == _device_list) return;
     dropReplicas();
     if (ordinals[0] != _device_ordinal || _device_list.empty()) markDeviceRebuild();
