@@ -44,7 +44,9 @@
 //       every evaluated node with a key <= k is still in the beam when the search moves past k (max_dist > k, or the
 //       beam is not full): then, whichever order the reference takes, each node with a key <= k has fewer than B
 //       better nodes at its turn, so all of them get expanded, the same links get evaluated, and beam, visited set
-//       and expanded set are the same once the last of them is done.  The check is therefore deferred (`pend`);
+//       and expanded set are the same once the last of them is done -- PROVIDED no equal keys meet where the beam is
+//       cut while the tied nodes are being expanded (of two evaluated neighbours with the key of the farthest member,
+//       the one whose row comes first is kept: `pend_cut`).  The check is therefore deferred (`pend`);
 //   (d) result: equal keys among the first K results or across the K-th boundary (std::sort's order).
 // Equal keys elsewhere in the beam decide nothing.  Each of the three spots is checked where it arises; a query
 // that hits one, or meets a NaN / infinite distance that could be admitted, is abandoned and searched again -- by the
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(WAVE, (CU == 1 && R == 1) ? 5 : FNV_SORTED_WAVES_PE
     if ((uint32_t)qi + ca->tail_exact >= ca->nq) tie = 5;  // last round of the launch: straight to the exact search
     float amb = INF;    // (a) pending: key at which the reference's eviction choice is unknown
     float pend = -INF;  // (b) pending: largest key at which two unexpanded members tied
+    bool pend_cut = false;  // ... and, while it is pending, equal keys met where the beam is cut (see the header)
     uint32_t n_dist = 0, n_hops = 0;
     __syncthreads();
 
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(WAVE, (CU == 1 && R == 1) ? 5 : FNV_SORTED_WAVES_PE
         break;
       }
       if (key_c > pend && pend > -INF) {  // (b) the search has moved past a tied key: was that tie harmless?
-        if (n >= B && !(max_dist > pend)) {
+        if (pend_cut || (n >= B && !(max_dist > pend))) {
           tie = 2;
           break;
         }
@@ -279,6 +282,9 @@ __global__ __launch_bounds__(WAVE, (CU == 1 && R == 1) ? 5 : FNV_SORTED_WAVES_PE
         const bool full0 = n >= B;
         const bool pass = lane < nn && (!full0 || d < max_dist);  // superset of what one-by-one admission lets in
         const unsigned long long pm = __ballot(pass);
+        // (b) while a selection tie is pending the order of the tied expansions is the reference's choice; a neighbour
+        // refused exactly at the cut (d == max_dist) would have been kept had its row come first
+        if (pend > -INF && full0 && __ballot(lane < nn && d == max_dist) != 0ull) pend_cut = true;
         if (pm != 0ull) {
           if (__ballot(pass && !(d < INF)) != 0ull) {  // NaN / infinite distance that could be admitted
             tie = 4;
@@ -413,7 +419,10 @@ __global__ __launch_bounds__(WAVE, (CU == 1 && R == 1) ? 5 : FNV_SORTED_WAVES_PE
             max_dist = rfl(unpack(beam[n - 1]).key);  // Index.h:702
           }
           // (a) an element left outside has the key of the new farthest member
-          if (__ballot(out_eq && out_key == max_dist) != 0ull) amb = max_dist;
+          if (__ballot(out_eq && out_key == max_dist) != 0ull) {
+            amb = max_dist;
+            if (pend > -INF) pend_cut = true;  // (b) likewise: which of the two is inside depends on the order
+          }
           if (max_dist < amb) amb = INF;  // every entry with that key is gone from both versions of the beam
           wave_sync();  // the LDS buffer is rewritten by the next merge
         }
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(WAVE, (CU == 1 && R == 1) ? 5 : FNV_SORTED_WAVES_PE
     ColdArgs c = cold_args();
     const int K = c->K;
     if (!tie && amb < INF) tie = 1;  // (a) still undecided when the search ended
-    if (!tie && pend > -INF && n >= B && !(max_dist > pend)) tie = 2;  // (b) likewise
+    if (!tie && pend > -INF && (pend_cut || (n >= B && !(max_dist > pend)))) tie = 2;  // (b) likewise
     const int cnt = n < K ? n : K;
     if (!tie && R == 0) {  // (d), LDS form
       for (int k0 = 0; k0 < cnt && !tie; k0 += WAVE) {

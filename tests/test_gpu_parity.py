@@ -314,6 +314,63 @@ def test_infinite_distances_go_to_the_exact_search(oracle_mod, hipmod):
                 assert dev.replayed_queries()["nan_inf"] > 0  # small beams fill up with whatever comes first
 
 
+def test_merged_beam_forms_agree_with_the_exact_kernel_on_random_shapes(oracle_mod, hipmod, tmp_path):
+    # Randomised sweep of the merged-beam kernel (one-chunk / four-chunk register forms, LDS form) against the exact
+    # two-heap kernel on GPU-built graphs: element types, metrics, row widths, link-row widths, beam widths and tie
+    # densities drawn at random; every sixth graph is also searched by the oracle.  (Trial 18 of this stream is the
+    # case that showed the selection-tie rule needed `pend_cut`: three unexpanded members with one key whose rows hold
+    # two neighbours with the key of the farthest member -- whichever row comes first keeps its neighbour.)
+    import ctypes
+    import flatnav_amd as flatnav
+
+    rng = np.random.default_rng(2026)
+    seen = set()
+    for trial in range(90):
+        dt = ["float32", "uint8", "int8"][trial % 3]
+        metric = ["l2", "angular"][int(rng.integers(0, 2))]
+        dim = int(rng.choice([8, 24, 32, 64, 100, 128, 200, 768]))
+        M = int(rng.choice([4, 8, 16, 32, 48, 70]))
+        N = int(rng.integers(800, 12000))
+        spread = int(rng.choice([2, 4, 16, 120]))  # few distinct values -> ties everywhere
+        if dt == "int8":
+            X = rng.integers(-spread, spread, (N, dim)).astype(np.int8); Q = rng.integers(-spread, spread, (256, dim)).astype(np.int8)
+        elif dt == "uint8":
+            X = rng.integers(0, 2 * spread, (N, dim)).astype(np.uint8); Q = rng.integers(0, 2 * spread, (256, dim)).astype(np.uint8)
+        else:
+            X = rng.integers(0, 2 * spread, (N, dim)).astype(np.float32); Q = rng.integers(0, 2 * spread, (256, dim)).astype(np.float32)
+        kw = {} if dt == "float32" else {"index_data_type": getattr(flatnav.data_type.DataType, dt)}
+        ix = flatnav.index.create(metric, dim, N, M, **kw)
+        ix.set_num_threads(4)
+        ix.add(X, 40, device=True)
+        dev = hipmod.DeviceIndex(ctypes.c_void_p(ix.device_handle()), owned=False)
+        oix = None
+        if trial % 6 == 0:
+            ix.save(str(tmp_path / "fuzz.bin"))
+            oix = oracle_mod.OracleIndex.load(str(tmp_path / "fuzz.bin"), "l2" if metric == "l2" else "ip")
+        for K, ef in ((1, int(rng.integers(1, 9))), (10, int(rng.integers(10, 65))), (int(rng.integers(1, 80)), int(rng.integers(65, 257))),
+                      (10, int(rng.integers(257, 700)))):
+            dev.set_option("sorted_beam", 0)
+            want = dev.search(Q, K, ef, stats=True)
+            if oix is not None:
+                _assert_exact(oix.search(Q, K, ef, stats=True, threads=8), want)
+            dev.set_option("sorted_beam", 1)
+            for regs in (1, 0):
+                dev.set_option("beam_registers", regs)
+                got = dev.search(Q, K, ef, stats=True)
+                name = dev.launch_geometry()["kernel"]
+                # ("two_heaps": indexes too small for the tagged visited table the merged-beam kernel needs)
+                assert name in ("merged_beam_registers" if regs and max(K, ef) <= 256 else "merged_beam_lds", "two_heaps")
+                seen.add(name)
+                try:
+                    _assert_exact(want, got)
+                except AssertionError as e:
+                    raise AssertionError("trial %d: %s %s d=%d M=%d N=%d spread=%d K=%d ef=%d %s: %s" % (
+                        trial, dt, metric, dim, M, N, spread, K, ef, name, e))
+        dev.set_option("sorted_beam", 2)
+        dev.set_option("beam_registers", 1)
+    assert {"merged_beam_registers", "merged_beam_lds"} <= seen
+
+
 def test_labels_and_duplicate_links(oracle_mod, hipmod):
     rng = np.random.default_rng(5)
     X = rng.integers(0, 256, (3000, 64)).astype(np.float32)
