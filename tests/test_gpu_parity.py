@@ -323,9 +323,12 @@ def test_merged_beam_forms_agree_with_the_exact_kernel_on_random_shapes(oracle_m
     import ctypes
     import flatnav_amd as flatnav
 
-    rng = np.random.default_rng(2026)
+    import os
+    rng = np.random.default_rng(int(os.environ.get("FNV_FUZZ_SEED", "2026")))
+    rng2 = np.random.default_rng(int(os.environ.get("FNV_FUZZ_SEED", "2026")) + 1)  # later additions: own stream
+    trials, oracle_every = int(os.environ.get("FNV_FUZZ_TRIALS", "90")), int(os.environ.get("FNV_FUZZ_ORACLE_EVERY", "6"))
     seen = set()
-    for trial in range(90):
+    for trial in range(trials):
         dt = ["float32", "uint8", "int8"][trial % 3]
         metric = ["l2", "angular"][int(rng.integers(0, 2))]
         dim = int(rng.choice([8, 24, 32, 64, 100, 128, 200, 768]))
@@ -338,17 +341,23 @@ def test_merged_beam_forms_agree_with_the_exact_kernel_on_random_shapes(oracle_m
             X = rng.integers(0, 2 * spread, (N, dim)).astype(np.uint8); Q = rng.integers(0, 2 * spread, (256, dim)).astype(np.uint8)
         else:
             X = rng.integers(0, 2 * spread, (N, dim)).astype(np.float32); Q = rng.integers(0, 2 * spread, (256, dim)).astype(np.float32)
+        real = None
+        if dt == "float32" and trial % 2 == 1:  # real-valued rows: both kernels share the arithmetic, so still bit for bit
+            real = rng2.standard_normal((N + 256, dim)).astype(np.float32)
+            X, Q = real[:N], real[N:]
         kw = {} if dt == "float32" else {"index_data_type": getattr(flatnav.data_type.DataType, dt)}
         ix = flatnav.index.create(metric, dim, N, M, **kw)
         ix.set_num_threads(4)
         ix.add(X, 40, device=True)
         dev = hipmod.DeviceIndex(ctypes.c_void_p(ix.device_handle()), owned=False)
         oix = None
-        if trial % 6 == 0:
+        if trial % oracle_every == 0 and real is None:  # (real-valued data: the oracle's sums are ordered differently)
             ix.save(str(tmp_path / "fuzz.bin"))
             oix = oracle_mod.OracleIndex.load(str(tmp_path / "fuzz.bin"), "l2" if metric == "l2" else "ip")
+        e1, e2 = int(rng2.integers(2, 40)), int(rng2.integers(40, 200))
+        dev.set_option("visited_slots", 256 if trial % 4 == 1 else 0)  # every fourth graph: most ids go to the HBM bitmap
         for K, ef in ((1, int(rng.integers(1, 9))), (10, int(rng.integers(10, 65))), (int(rng.integers(1, 80)), int(rng.integers(65, 257))),
-                      (10, int(rng.integers(257, 700)))):
+                      (10, int(rng.integers(257, 700))), (e1, e1), (e2, e2)):  # K == ef: every beam member is a result
             dev.set_option("sorted_beam", 0)
             want = dev.search(Q, K, ef, stats=True)
             if oix is not None:
@@ -368,6 +377,7 @@ def test_merged_beam_forms_agree_with_the_exact_kernel_on_random_shapes(oracle_m
                         trial, dt, metric, dim, M, N, spread, K, ef, name, e))
         dev.set_option("sorted_beam", 2)
         dev.set_option("beam_registers", 1)
+        dev.set_option("visited_slots", 0)
     assert {"merged_beam_registers", "merged_beam_lds"} <= seen
 
 
