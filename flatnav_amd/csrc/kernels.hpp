@@ -385,10 +385,15 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, int qi, uint32_t 
     // Exact replay of the reference's tail: pop everything (descending), std::sort ascending.
     for (int m = n; m > 1; m--) coop_pop<true>(nbr, m, lane, ph, 7);  // leaves nbr[] ascending
     __syncthreads();
-    for (int i = lane; i < n; i += WAVE) res[i] = nbr.p[n - 1 - i];  // pop order = descending
+    // Construction (node ids out, the whole beam asked for): the reference hands the beam's heap itself to
+    // selectNeighbors / connectNeighbors, and when it holds fewer entries than there are slots to fill
+    // (Index.h:715-717) it is popped as it is -- so the caller needs the POP ORDER, not std::sort's: the list
+    // goes out closest first = pop order reversed (csrc/wire.hpp reads it backwards in that case).
+    const bool pop_order_out = cold_args()->labels == nullptr && n <= K;
+    for (int i = lane; i < n; i += WAVE) res[i] = pop_order_out ? nbr.p[i] : nbr.p[n - 1 - i];  // pop order = descending
     if (res_global) __threadfence_block();
     __syncthreads();
-    if (lane == 0) {
+    if (lane == 0 && !pop_order_out) {
       LdsHeap r{res};
       // introsort's explicit stack lives in the (now dead) visited table: >= 512 bytes = 42 frames, the
       // library's depth limit 2*lg(n) needs at most 25 for beams that fit in LDS

@@ -213,16 +213,19 @@ __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void wire_select_kern
     wave_sync();
     rank_order(ckey, cid, C, okey, oid, lane);
     int kept_n;
-    if (C < (int)p.keep) {  // Index.h:716-718: fewer candidates than slots -- all of them
-      for (int j = lane; j < C; j += WAVE) kept[j] = (uint32_t)j;
+    if (C < (int)p.keep) {
+      // Index.h:715-717: fewer candidates than slots -- all of them, and the beam's own heap is popped as it is: the
+      // search wrote the beam closest first with equal distances in reverse pop order (kernels.hpp, result tail)
+      for (int j = lane; j < C; j += WAVE) sel[j] = cid[C - 1 - j];
       kept_n = C;
       wave_sync();
     } else {
       kept_n = prune_ordered<T, METRIC, G, CU, FULL>(p, qlds, okey, oid, C, (int)p.keep, alive, kept, stage_ids,
                                                      stage_idx, lane);
+      // ---- kept nodes in the reference's pop order ----------------------------------------------------------
+      pop_order(okey, oid, kept, kept_n, reinterpret_cast<unsigned long long*>(alive), sel, lane);
     }
-    // ---- u's own row: kept nodes in the reference's pop order, then empty (self-loop) slots ---------
-    pop_order(okey, oid, kept, kept_n, reinterpret_cast<unsigned long long*>(alive), sel, lane);
+    // ---- u's own row: kept nodes, then empty (self-loop) slots ----------------------------------------
     for (int j = lane; j < M; j += WAVE) p.links[(uint64_t)u * p.M + j] = j < kept_n ? sel[j] : u;
     // ---- the back-link requests (Index.h:783: "add the reverse edge"), in the order the row lists them ----
     for (int t = lane; t < (int)p.keep; t += WAVE) p.req_target[i * p.keep + (uint32_t)t] = t < kept_n ? sel[t] : EMPTY_ID;

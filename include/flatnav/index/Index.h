@@ -334,13 +334,16 @@ class Index {
   // Wire the new node to its selected neighbours and add back-links (reference connectNeighbors,
   // Index.h:765-834): a back-link takes the neighbour's first free (self-loop) slot, otherwise the
   // neighbour's row is re-pruned over {old links} + {new node}.
-  void linkNeighbors(detail::KeyHeap& selected, node_id_t new_id, detail::BuildScratch& s) {
+  // `pop_order` (optional): the neighbours in the order the reference would pop them, for callers that know it without
+  // holding the heap itself (beams searched on the GPU); `selected` is then only emptied.
+  void linkNeighbors(detail::KeyHeap& selected, node_id_t new_id, detail::BuildScratch& s,
+                     const node_id_t* pop_order = nullptr) {
     detail::NodeGuard own(_node_locks, new_id);
     node_id_t* new_links = nodeLinks(new_id);
     _dirty_rows.mark(new_id);
     size_t slot = 0;
     while (!selected.empty()) {
-      const node_id_t nb = selected.top().val;
+      const node_id_t nb = pop_order ? pop_order[slot] : selected.top().val;
       new_links[slot++] = nb;
       _dirty_rows.mark(nb);
       {
@@ -720,7 +723,12 @@ class Index {
         const node_id_t new_id = static_cast<node_id_t>(cur + i);
         mine[n_mine++] = new_id;
         for (int j = 0; j < beam.size() && n_mine < 65; ++j) mine[n_mine++] = beam.a.items[static_cast<size_t>(j)].val;
-        linkNeighbors(beam, new_id, *scratch);
+        // Fewer candidates than slots: the reference pops the search's own heap as it is (Index.h:715-717); the
+        // device wrote that beam closest first with equal distances in reverse pop order, so read it backwards.
+        node_id_t as_popped[64];
+        const bool untouched = beam_count[i] < keep && beam_count[i] <= 64;
+        for (int j = 0; untouched && j < beam_count[i]; ++j) as_popped[j] = static_cast<node_id_t>(bi[beam_count[i] - 1 - j]);
+        linkNeighbors(beam, new_id, *scratch, untouched ? as_popped : nullptr);
         returnScratch(std::move(scratch));
         std::lock_guard<std::mutex> g(touched_guard);
         touched.insert(touched.end(), mine, mine + n_mine);

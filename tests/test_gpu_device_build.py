@@ -165,6 +165,36 @@ def test_sequential_device_insertion_reproduces_the_oracle_graph(flatnav, oracle
     assert bad.size == 0, "first differing node %d of %d differing" % (bad[0], bad.size)
 
 
+def test_sequential_device_insertion_on_random_shapes(flatnav, oracle_mod):
+    # The same property over randomly drawn shapes: element type, metric, row width, link-row width, ef_construction,
+    # tie density (FNV_FUZZ_TRIALS / FNV_FUZZ_SEED deepen the sweep).
+    import os
+    rng = np.random.default_rng(int(os.environ.get("FNV_FUZZ_SEED", "77")))
+    for trial in range(int(os.environ.get("FNV_FUZZ_TRIALS", "16"))):
+        dt = ["float32", "uint8", "int8"][trial % 3]
+        metric = ["l2", "angular"][int(rng.integers(0, 2))]
+        dim = int(rng.choice([4, 16, 33, 64, 128, 200]))
+        M = int(rng.choice([2, 4, 8, 16, 32]))
+        N = int(rng.integers(300, 1500))
+        efc = int(rng.choice([5, 20, 40, 100]))
+        hi = int(rng.choice([2, 4, 16, 100]))
+        lo = -hi // 2 if dt == "int8" else 0
+        X = rng.integers(lo, lo + hi, (N, dim)).astype(dt)
+        o = oracle_mod.OracleIndex.create(metric, dim, N, M, dt)
+        o.add(X, efc)
+        ix = flatnav.index.create(metric, dim, N, M, getattr(flatnav.data_type.DataType, dt))
+        boot = int(rng.choice([1, 8, 40]))
+        if os.environ.get("FNV_FUZZ_BOOTSTRAP"):
+            boot = int(os.environ["FNV_FUZZ_BOOTSTRAP"])
+        # (odd trials: beam searches on the GPU, pruning / wiring by the host code -- the same sequential algorithm)
+        ix.add(X, efc, device=True, device_max_batch=1, device_bootstrap=boot, device_wiring=trial % 2 == 0)
+        want = np.asarray(o.blob())[: N * o.node_size].reshape(N, o.node_size)
+        got = np.asarray(ix._raw_blob())[: N * o.node_size].reshape(N, o.node_size)
+        bad = np.flatnonzero((want != got).any(axis=1))
+        assert bad.size == 0, "trial %d (%s %s d=%d M=%d N=%d efc=%d hi=%d boot=%d): first differing node %d of %d differing" % (
+            trial, dt, metric, dim, M, N, efc, hi, boot, bad[0], bad.size)
+
+
 def test_batched_device_build_is_deterministic(flatnav):
     # Same data, same options -> same bytes, run after run (requests are grouped by a stable sort, not by arrival).
     N, M = 30000, 32
