@@ -372,6 +372,10 @@ def test_merged_beam_forms_agree_with_the_exact_kernel_on_random_shapes(oracle_m
                 seen.add(name)
                 try:
                     _assert_exact(want, got)
+                    if regs and trial % 3 == 0:  # the answer to a query does not depend on what it is batched with
+                        for a, b in ((0, 1), (5, 70)):
+                            part = dev.search(Q[a:b], K, ef, stats=True)
+                            _assert_exact((want[0][a:b], want[1][a:b], {k: v[a:b] for k, v in want[2].items()}), part)
                 except AssertionError as e:
                     raise AssertionError("trial %d: %s %s d=%d M=%d N=%d spread=%d K=%d ef=%d %s: %s" % (
                         trial, dt, metric, dim, M, N, spread, K, ef, name, e))

@@ -76,6 +76,30 @@ def test_single_thread_build_equals_oracle_graph(flatnav, oracle_mod, tmp_path, 
     assert np.array_equal(o2.blob(), o.blob())
 
 
+def test_single_thread_build_equals_oracle_graph_on_random_shapes(flatnav, oracle_mod):
+    # The host builder against the oracle's graph bytes over randomly drawn shapes: element type, metric, row width, M,
+    # ef_construction (also smaller than M/2: the beam is then wired as its heap pops it), tie density.
+    rng = np.random.default_rng(int(os.environ.get("FNV_FUZZ_SEED", "404")))
+    for trial in range(int(os.environ.get("FNV_FUZZ_TRIALS", "24"))):
+        dt = ["float32", "uint8", "int8"][trial % 3]
+        metric = ["l2", "angular"][int(rng.integers(0, 2))]
+        dim = int(rng.choice([3, 16, 33, 100]))
+        M = int(rng.choice([2, 4, 8, 16, 32]))
+        N = int(rng.integers(50, 900))
+        efc = int(rng.choice([3, 10, 40, 100]))
+        hi = int(rng.choice([2, 4, 16, 100]))
+        lo = -hi // 2 if dt == "int8" else 0
+        X = rng.integers(lo, lo + hi, (N, dim)).astype(dt)
+        kw = {} if dt == "float32" else {"index_data_type": getattr(flatnav.data_type.DataType, dt)}
+        ix = flatnav.index.create(metric, dim, N, M, **kw)
+        ix.set_num_threads(1)
+        ix.add(X, efc)
+        o = oracle_mod.OracleIndex.create(metric, dim, N, M, dt)
+        o.add(X, efc)
+        assert np.array_equal(np.asarray(ix._raw_blob()), o.blob()), "trial %d: %s %s d=%d M=%d N=%d efc=%d hi=%d" % (
+            trial, dt, metric, dim, M, N, efc, hi)
+
+
 def test_forcecast_and_labels(flatnav, oracle_mod):
     X = _data("float32", 500, 16, 3)
     ix = flatnav.index.create("l2", 16, 500, 8)
