@@ -356,16 +356,19 @@ def test_merged_beam_forms_agree_with_the_exact_kernel_on_random_shapes(oracle_m
             oix = oracle_mod.OracleIndex.load(str(tmp_path / "fuzz.bin"), "l2" if metric == "l2" else "ip")
         e1, e2 = int(rng2.integers(2, 40)), int(rng2.integers(40, 200))
         dev.set_option("visited_slots", 256 if trial % 4 == 1 else 0)  # every fourth graph: most ids go to the HBM bitmap
+        dev.set_option("visited_tag_bits", [0, 0, 32, 0, 21][trial % 5])  # the wide-tag tables of indexes beyond 2^24 nodes
+        dev.set_option("entry_kernel", 1 if trial % 7 == 3 else 0)      # entry points from the batch scan kernel (K0)
+        n_init = [100, 100, 1, 7, 100000][trial % 5]                    # Index.h:845-870: ceil(N / step) fixed nodes
         for K, ef in ((1, int(rng.integers(1, 9))), (10, int(rng.integers(10, 65))), (int(rng.integers(1, 80)), int(rng.integers(65, 257))),
                       (10, int(rng.integers(257, 700))), (e1, e1), (e2, e2)):  # K == ef: every beam member is a result
             dev.set_option("sorted_beam", 0)
-            want = dev.search(Q, K, ef, stats=True)
+            want = dev.search(Q, K, ef, n_init, stats=True)
             if oix is not None:
-                _assert_exact(oix.search(Q, K, ef, stats=True, threads=8), want)
+                _assert_exact(oix.search(Q, K, ef, n_init, stats=True, threads=8), want)
             dev.set_option("sorted_beam", 1)
             for regs in (1, 0):
                 dev.set_option("beam_registers", regs)
-                got = dev.search(Q, K, ef, stats=True)
+                got = dev.search(Q, K, ef, n_init, stats=True)
                 name = dev.launch_geometry()["kernel"]
                 # ("two_heaps": indexes too small for the tagged visited table the merged-beam kernel needs)
                 assert name in ("merged_beam_registers" if regs and max(K, ef) <= 256 else "merged_beam_lds", "two_heaps")
@@ -374,7 +377,7 @@ def test_merged_beam_forms_agree_with_the_exact_kernel_on_random_shapes(oracle_m
                     _assert_exact(want, got)
                     if regs and trial % 3 == 0:  # the answer to a query does not depend on what it is batched with
                         for a, b in ((0, 1), (5, 70)):
-                            part = dev.search(Q[a:b], K, ef, stats=True)
+                            part = dev.search(Q[a:b], K, ef, n_init, stats=True)
                             _assert_exact((want[0][a:b], want[1][a:b], {k: v[a:b] for k, v in want[2].items()}), part)
                 except AssertionError as e:
                     raise AssertionError("trial %d: %s %s d=%d M=%d N=%d spread=%d K=%d ef=%d %s: %s" % (
@@ -382,6 +385,8 @@ def test_merged_beam_forms_agree_with_the_exact_kernel_on_random_shapes(oracle_m
         dev.set_option("sorted_beam", 2)
         dev.set_option("beam_registers", 1)
         dev.set_option("visited_slots", 0)
+        dev.set_option("visited_tag_bits", 0)
+        dev.set_option("entry_kernel", 0)
     assert {"merged_beam_registers", "merged_beam_lds"} <= seen
 
 
