@@ -195,6 +195,40 @@ def test_sequential_device_insertion_on_random_shapes(flatnav, oracle_mod):
             trial, dt, metric, dim, M, N, efc, hi, boot, bad[0], bad.size)
 
 
+def test_batched_device_builds_on_random_shapes_are_valid_graphs(flatnav):
+    # Batched insertion over randomly drawn shapes: every row holds distinct in-range neighbours (self id = empty slot),
+    # every node is wired, the same call gives the same bytes, and the graph finds its own points.
+    import os
+    rng = np.random.default_rng(int(os.environ.get("FNV_FUZZ_SEED", "99")))
+    for trial in range(int(os.environ.get("FNV_FUZZ_TRIALS", "8"))):
+        dt = ["float32", "uint8", "int8"][trial % 3]
+        metric = "l2" if trial % 2 == 0 else "angular"
+        dim = int(rng.choice([8, 32, 100, 128]))
+        M = int(rng.choice([4, 8, 16, 32, 48]))
+        N = int(rng.integers(3000, 20000))
+        efc = int(rng.choice([20, 64, 100]))
+        batch = int(rng.choice([7, 256, 4096]))
+        boot = int(rng.choice([64, 2048]))
+        hi = int(rng.choice([4, 16, 100]))
+        lo = -hi // 2 if dt == "int8" else 0
+        X = rng.integers(lo, lo + hi, (N, dim)).astype(dt)
+        what = "trial %d: %s %s d=%d M=%d N=%d efc=%d batch=%d boot=%d hi=%d" % (trial, dt, metric, dim, M, N, efc, batch, boot, hi)
+        blobs = []
+        for _ in range(2 if trial % 4 == 0 else 1):
+            ix = flatnav.index.create(metric, dim, N, M, getattr(flatnav.data_type.DataType, dt))
+            ix.set_num_threads(4)
+            ix.add(X, efc, device=True, device_max_batch=batch, device_bootstrap=boot)
+            blobs.append(np.asarray(ix._raw_blob()).copy())
+        assert len(blobs) == 1 or np.array_equal(blobs[0], blobs[1]), what
+        _check_graph(ix, N, M)
+        if metric == "l2" and hi >= 16 and M >= 8 and trial % 3 != 2:  # distinct points: how often does a node find itself,
+            host = flatnav.index.create(metric, dim, N, M, getattr(flatnav.data_type.DataType, dt))  # against the host builder
+            host.set_num_threads(4)
+            host.add(X, efc)
+            found = [float((g.search(X[:300], 1, 64)[0][:, 0] == 0).mean()) for g in (ix, host)]
+            assert found[0] > found[1] - 0.1, what + " self-recall device %.2f host %.2f" % tuple(found)
+
+
 def test_batched_device_build_is_deterministic(flatnav):
     # Same data, same options -> same bytes, run after run (requests are grouped by a stable sort, not by arrival).
     N, M = 30000, 32
