@@ -79,3 +79,34 @@ def test_bench_spawns_its_own_ranks_and_runs_other_configs():
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 2 and d["config"]["workload"].startswith("c4 ") and d["value"] > 0
     assert d["roofline"]["frac_of_achievable"] > d["roofline"]["frac"] > 0
+
+
+@pytest.mark.parametrize("metric", ["l2", "angular"])
+def test_bench_ground_truth_equals_numpy_brute_force(metric):
+    # bench.py's recall is measured against exact_topk() (GEMM shortlist + exact re-rank on the index's own HBM vector
+    # table); the float64 numpy brute force of flatnav_amd/datasets.py must give the same neighbour sets.
+    import ctypes
+
+    import numpy as np
+    import torch
+
+    sys.path.insert(0, ROOT)
+    import bench
+    import flatnav_amd as flatnav
+    from flatnav_amd import datasets as ds, hip
+
+    N, NQ, K = 30000, 700, 10
+    if metric == "l2":
+        X, Q = ds.sift_like(N, NQ)
+        truth = ds.exact_topk_l2(X, Q, K)
+    else:
+        X, Q = ds.lowrank_normalized(N, NQ, dim=100, rank=24, seed=100)
+        truth = ds.exact_topk_ip(X, Q, K)
+    ix = flatnav.index.create(metric, X.shape[1], N, 16)
+    ix.set_num_threads(4)
+    ix.add(X, 40, device=True)
+    dev = hip.DeviceIndex(ctypes.c_void_p(ix.device_handle()), owned=False)
+    got = bench.exact_topk(torch, dev, torch.from_numpy(Q).cuda(), K, N, X.shape[1], "float32",
+                           "l2" if metric == "l2" else "ip", block=7000).cpu().numpy()
+    same = np.mean([len(set(a.tolist()) & set(b.tolist())) for a, b in zip(got, truth)]) / K
+    assert same > 0.9995  # equal distances at the K-th place may resolve differently; everything else must agree
