@@ -759,10 +759,11 @@ class Index {
       if (_num_threads == 1) for (uint32_t n = 0; n < _cur_num_nodes; ++n) unpackRow(n);
       else flatnav::executeInParallel(0, static_cast<uint32_t>(_cur_num_nodes), _num_threads, unpackRow);
     }
-    // the device copy was kept in step
+    // the device copy was kept in step; replicas on other GPUs were not
     _dirty_rows.drain(0);
     _device_synced_nodes = _cur_num_nodes;
     _device_stale = _device_rebuild = false;
+    _replicas_stale = true;
   }
 
   void add(void* data, label_t& label, int ef_construction, int num_initializations) {

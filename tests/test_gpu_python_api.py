@@ -124,3 +124,64 @@ def test_concurrent_callers_on_one_index(flatnav, oracle_mod):
     for i in range(6):
         assert np.array_equal(got[i][0], want[0][i * 200:(i + 1) * 200])
         assert np.array_equal(got[i][1], want[1][i * 200:(i + 1) * 200])
+
+
+def test_random_operation_sequences_keep_the_device_copy_in_step(flatnav, oracle_mod, tmp_path):
+    # Model-based: random interleavings of add (host builder / device builder / sequential device insertion), search,
+    # save + load, reorder and set_devices; after every step the GPU's answers must equal the oracle's on the index's
+    # current node store (integer-valued data: bit for bit).  Catches a device mirror that lags behind the host index.
+    import os
+
+    rng = np.random.default_rng(int(os.environ.get("FNV_FUZZ_SEED", "31")))
+    for trial in range(int(os.environ.get("FNV_FUZZ_TRIALS", "15"))):
+        dt = ["float32", "uint8", "int8"][trial % 3]
+        metric = ["l2", "angular"][int(rng.integers(0, 2))]
+        dim, M = int(rng.choice([16, 48, 128])), int(rng.choice([8, 16, 32]))
+        cap = int(rng.integers(3000, 9000))
+        hi = int(rng.choice([4, 30, 100]))
+        lo = -hi // 2 if dt == "int8" else 0
+        X = rng.integers(lo, lo + hi, (cap, dim)).astype(dt)
+        Q = rng.integers(lo, lo + hi, (300, dim)).astype(dt)
+        ix = flatnav.index.create(metric, dim, cap, M, getattr(flatnav.data_type.DataType, dt))
+        ix.set_num_threads(1 if trial % 2 else 4)
+        filled, log = 0, []
+
+        def check(step):
+            if filled == 0:
+                return
+            K, ef = int(rng.integers(1, 12)), int(rng.integers(12, 150))
+            o = oracle_mod.OracleIndex.from_blob("l2" if metric == "l2" else "ip", dt, dim, cap, filled, M,
+                                                 np.asarray(ix._raw_blob()))
+            try:
+                od, ol = o.search(Q, K, ef)
+            except Exception:
+                return
+            if (ol < 0).any():
+                with pytest.raises(RuntimeError):  # fewer than K reachable results: the binding raises (bindings.cpp:184-189)
+                    ix.search(Q, K, ef)
+                return
+            gd, gl = ix.search(Q, K, ef)
+            assert np.array_equal(gl, ol) and np.array_equal(gd.view(np.uint32), od.view(np.uint32)), \
+                "trial %d after %s (%s %s d=%d M=%d filled=%d K=%d ef=%d)" % (trial, log, dt, metric, dim, M, filled, K, ef)
+
+        for step in range(int(rng.integers(4, 9))):
+            op = rng.choice(["add_host", "add_device", "add_seq", "save_load", "reorder", "devices", "search"])
+            if op.startswith("add") and filled < cap:
+                n = int(min(cap - filled, rng.integers(1, 2500)))
+                kw = {"add_host": {}, "add_device": dict(device=True, device_max_batch=int(rng.choice([64, 1024]))),
+                      "add_seq": dict(device=True, device_max_batch=1, device_bootstrap=int(rng.choice([1, 40])))}[op]
+                if op == "add_seq":
+                    n = min(n, 300)
+                ix.add(X[filled:filled + n], int(rng.choice([16, 64])), labels=list(range(filled, filled + n)), **kw)
+                filled += n
+            elif op == "save_load" and filled:
+                path = str(tmp_path / ("seq%d_%d.bin" % (trial, step)))
+                ix.save(path)
+                ix = type(ix).load_index(path)
+                ix.set_num_threads(2)
+            elif op == "reorder" and filled > 100:
+                ix.reorder([str(rng.choice(["gorder", "rcm"]))])
+            elif op == "devices":
+                ix.set_devices([0, 0] if rng.integers(0, 2) else [0])
+            log.append(op)
+            check(step)
