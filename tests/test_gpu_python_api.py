@@ -145,6 +145,7 @@ def test_random_operation_sequences_keep_the_device_copy_in_step(flatnav, oracle
         ix = flatnav.index.create(metric, dim, cap, M, getattr(flatnav.data_type.DataType, dt))
         ix.set_num_threads(1 if trial % 2 else 4)
         filled, log = 0, []
+        label_of = rng.permutation(cap) * 7 + int(rng.integers(0, 1000))  # labels are not node ids
 
         def check(step):
             if filled == 0:
@@ -161,8 +162,11 @@ def test_random_operation_sequences_keep_the_device_copy_in_step(flatnav, oracle
                     ix.search(Q, K, ef)
                 return
             gd, gl = ix.search(Q, K, ef)
-            assert np.array_equal(gl, ol) and np.array_equal(gd.view(np.uint32), od.view(np.uint32)), \
-                "trial %d after %s (%s %s d=%d M=%d filled=%d K=%d ef=%d)" % (trial, log, dt, metric, dim, M, filled, K, ef)
+            what = "trial %d after %s (%s %s d=%d M=%d filled=%d K=%d ef=%d)" % (trial, log, dt, metric, dim, M, filled, K, ef)
+            assert np.array_equal(gl, ol) and np.array_equal(gd.view(np.uint32), od.view(np.uint32)), what
+            q = int(rng.integers(0, len(Q)))  # the one-query entry point answers like the batch
+            sd, sl = ix.search_single(Q[q], K, ef)
+            assert np.array_equal(np.asarray(sl).ravel(), ol[q]) and np.array_equal(np.asarray(sd, dtype=np.float32).ravel(), od[q]), what
 
         for step in range(int(rng.integers(4, 9))):
             op = rng.choice(["add_host", "add_device", "add_seq", "save_load", "reorder", "devices", "search"])
@@ -172,7 +176,7 @@ def test_random_operation_sequences_keep_the_device_copy_in_step(flatnav, oracle
                       "add_seq": dict(device=True, device_max_batch=1, device_bootstrap=int(rng.choice([1, 40])))}[op]
                 if op == "add_seq":
                     n = min(n, 300)
-                ix.add(X[filled:filled + n], int(rng.choice([16, 64])), labels=list(range(filled, filled + n)), **kw)
+                ix.add(X[filled:filled + n], int(rng.choice([16, 64])), labels=[int(v) for v in label_of[filled:filled + n]], **kw)
                 filled += n
             elif op == "save_load" and filled:
                 path = str(tmp_path / ("seq%d_%d.bin" % (trial, step)))
