@@ -31,6 +31,17 @@ def test_c_abi_replicas_answer_like_the_source(oracle_mod):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
         for k in ("count", "n_dist", "n_hops"):
             assert np.array_equal(want[2][k], got[2][k])
+    # random batch sizes, beam shapes and replica counts (up to five handles on the one GPU)
+    rng = np.random.default_rng(3)
+    more = src.replicate([0, 0])
+    for _ in range(12):
+        G, nq = int(rng.integers(1, 6)), int(rng.integers(1, 900))
+        K, ef = int(rng.integers(1, 20)), int(rng.integers(20, 300))
+        first = int(rng.integers(0, len(Q) - nq))
+        ref = src.search(Q[first:first + nq], K, ef, stats=True)
+        got = hip.search_multi(([src] + replicas + more)[:G], Q[first:first + nq], K, ef, stats=True)
+        assert np.array_equal(ref[1], got[1]) and np.array_equal(ref[0].view(np.uint32), got[0].view(np.uint32)), (G, nq, K, ef)
+        assert all(np.array_equal(ref[2][k], got[2][k]) for k in ("count", "n_dist", "n_hops")), (G, nq, K, ef)
     # fewer rows than handles, and an empty batch
     d, l = hip.search_multi([src] + replicas, Q[:2], 10, 80)
     assert np.array_equal(l, want[1][:2])
