@@ -314,8 +314,8 @@ def main() -> None:
             dev.search_device(dq[i % nb].data_ptr(), NQ, K, ef, 100, d_dist.data_ptr(), d_lab.data_ptr(),
                               d_cnt.data_ptr(), d_nd.data_ptr(), d_nh.data_ptr(), stream=stream.cuda_stream)
         if ef not in settled:  # the library's per-beam-width kernel choice: three timed samples of each of its (up to
-            settled.add(ef)    # three) variants, harvested by the following call -- set-up, like a JIT's first calls
-            for i in range(11):
+            settled.add(ef)    # five) variants, harvested by the following call -- set-up, like a JIT's first calls
+            for i in range(17):
                 step(i)
                 torch.cuda.synchronize()
         for i in range(warmup):

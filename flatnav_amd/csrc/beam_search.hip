@@ -177,10 +177,10 @@ struct fnv_index_s {
   LaunchPlan plan;
   // adaptive kernel choice ("sorted_beam" = 2): per beam width, the best time per query seen for each variant
   struct Tuner {
-    // ms per query: [0] two-heap kernel, [1] merged-beam kernel, [2] merged-beam kernel whose last round of queries
-    // goes straight to the exact search ("sorted_tail_exact_pct" = 100; only launches of more than one round)
-    float best[3] = {-1.f, -1.f, -1.f};
-    int samples[3] = {0, 0, 0};
+    // ms per query: [0] two-heap kernel, [1] merged-beam kernel, [2..4] merged-beam kernel whose last 50 / 75 / 100 %
+    // of a round of queries go straight to the exact search ("sorted_tail_exact_pct"; launches of more than one round)
+    float best[5] = {-1.f, -1.f, -1.f, -1.f, -1.f};
+    int samples[5] = {0, 0, 0, 0, 0};
   };
   std::map<int, Tuner> tuner;
   int sample_B = 0, sample_kernel = -1;  // the launch between ev0 / ev1 is a sample for this entry (-1: it is not)
@@ -793,16 +793,19 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
       fnv_index_s::Tuner& t = ix->tuner[2 * B + (multi_round ? 1 : 0)];
       const bool try_tail = multi_round && ix->sorted_tail_exact_pct < 0;
       // three samples each (the first launch of a kernel is a cold one; the best of the rest decides), then the fastest
-      if (t.samples[1] < 3) variant = 1;
-      else if (t.samples[0] < 3) variant = 0;
-      else if (try_tail && t.samples[2] < 3) variant = 2;
-      else {
-        variant = t.best[1] <= t.best[0] ? 1 : 0;
-        if (try_tail && t.best[2] < t.best[variant]) variant = 2;
+      static const int kTailPct[5] = {0, 0, 50, 75, 100};
+      const int nvar = try_tail ? 5 : 2;
+      variant = -1;
+      for (int v : {1, 0, 4, 3, 2})
+        if (v < nvar && variant < 0 && t.samples[v] < 3) variant = v;
+      if (variant < 0) {
+        variant = 0;
+        for (int v = 1; v < nvar; v++)
+          if (t.best[v] < t.best[variant] || (v == 1 && t.best[1] <= t.best[0])) variant = v;
       }
       sample = t.samples[variant] < 4;
       sorted = variant != 0;
-      if (variant == 2) tail_pct = 100;
+      if (variant >= 2) tail_pct = kTailPct[variant];
     }
   }
   const int bpc = sorted ? plan.sbpc : plan.bpc;

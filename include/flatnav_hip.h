@@ -164,7 +164,7 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *   "sorted_tail_exact_pct"  the last p % of one round of queries (one round = as many queries as stay resident)
  *                     of a merged-beam launch go straight to the exact search: a query that is searched twice
  *                     finishes late, and in the last round that lengthens the whole launch.  -1 (default) = one more
- *                     variant for the adaptive choice to measure (0 or 100); >= 0 = fixed
+ *                     variant for the adaptive choice to measure (it tries 0, 50, 75 and 100); >= 0 = fixed
  *   "beam_registers"  != 0 (default): beams of at most 256 entries keep the sorted array in registers (the merge's
  *                     permutation goes through LDS); 0 = the array always lives in LDS, as it does for wider beams
  *   "sorted_beam_min" smallest beam width the merged-beam kernel is used for (default 1)
