@@ -76,7 +76,7 @@ def test_single_thread_build_equals_oracle_graph(flatnav, oracle_mod, tmp_path, 
     assert np.array_equal(o2.blob(), o.blob())
 
 
-def test_single_thread_build_equals_oracle_graph_on_random_shapes(flatnav, oracle_mod):
+def test_single_thread_build_equals_oracle_graph_on_random_shapes(flatnav, oracle_mod, tmp_path):
     # The host builder against the oracle's graph bytes over randomly drawn shapes: element type, metric, row width, M,
     # ef_construction (also smaller than M/2: the beam is then wired as its heap pops it), tie density.
     rng = np.random.default_rng(int(os.environ.get("FNV_FUZZ_SEED", "404")))
@@ -96,8 +96,15 @@ def test_single_thread_build_equals_oracle_graph_on_random_shapes(flatnav, oracl
         ix.add(X, efc)
         o = oracle_mod.OracleIndex.create(metric, dim, N, M, dt)
         o.add(X, efc)
-        assert np.array_equal(np.asarray(ix._raw_blob()), o.blob()), "trial %d: %s %s d=%d M=%d N=%d efc=%d hi=%d" % (
-            trial, dt, metric, dim, M, N, efc, hi)
+        what = "trial %d: %s %s d=%d M=%d N=%d efc=%d hi=%d" % (trial, dt, metric, dim, M, N, efc, hi)
+        assert np.array_equal(np.asarray(ix._raw_blob()), o.blob()), what
+        if trial % 3 == 0:  # the files: byte-identical, and each side loads the other's
+            p1, p2 = str(tmp_path / "a.bin"), str(tmp_path / "b.bin")
+            ix.save(p1)
+            o.save(p2)
+            assert open(p1, "rb").read() == open(p2, "rb").read(), what
+            assert np.array_equal(np.asarray(type(ix).load_index(p2)._raw_blob()), o.blob()), what
+            assert np.array_equal(oracle_mod.OracleIndex.load(p1, "l2" if metric == "l2" else "ip").blob(), o.blob()), what
 
 
 def test_forcecast_and_labels(flatnav, oracle_mod):
