@@ -122,16 +122,16 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : FNV_SORTED_WAVES_PER_SIMD) void
     const uint32_t* const links = ca->links;
     const uint32_t row_bytes = ca->row_bytes;
     const int nchunks = (int)ca->nchunks;
-    const int B = ca->B;  // <= R * WAVE
+    const int B = ca->B;  // register forms: <= R * WAVE
     const int M = (int)ca->M;
     const VisGeom vg{ca->vis_nmask, ca->vis_rshift, ca->vis_rmask, ca->vis_mult, ca->vis_w};
     uint4* qlds = reinterpret_cast<uint4*>(smem + ca->off_q);
     uint32_t* vis = reinterpret_cast<uint32_t*>(smem + ca->off_vis);
     uint32_t* stage_ids = reinterpret_cast<uint32_t*>(smem + ca->off_stage_ids);
-    float* stage_d = reinterpret_cast<float*>(smem + ca->off_stage_d);  // aliases `beam` below: used between merges
+    float* stage_d = reinterpret_cast<float*>(smem + ca->off_stage_d);  // register forms: aliases `beam` (used between merges)
     uint32_t* ovf_list = reinterpret_cast<uint32_t*>(smem + ca->off_ovf);
-    // [B + 2] at 16n + 8 (word -1 = write-only bin): the merge's permutation buffer, and the neighbours heap of an
-    // exact re-run
+    // [B + 2] at 16n + 8 (word -1 = write-only bin): the merge's permutation buffer (register forms) or the beam itself
+    // (LDS form), and the neighbours heap of an exact re-run
     unsigned long long* beam = reinterpret_cast<unsigned long long*>(smem + ca->off_nbr);
     stage_query<T>(qlds, vis, ovf_list, qi, true, lane);
     __syncthreads();
