@@ -90,6 +90,7 @@ const KernelTable& kernel_table(int, int) {
         k.merged[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, MB_R>;
         k.merged1[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, 1>;
         k.merged0[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, 0>;
+        k.merged2[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, 2>;
         k.select[c][f] = wire_select_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
         k.connect[c][f] = wire_connect_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
       }
@@ -109,6 +110,7 @@ const KernelTable& kernel_table(int dtype, int metric) {
     fill_merged_##tag##_##mtag(tables[i]);      \
     fill_merged1_##tag##_##mtag(tables[i]);     \
     fill_merged0_##tag##_##mtag(tables[i]);     \
+    fill_merged2_##tag##_##mtag(tables[i]);     \
     fill_wire_##tag##_##mtag(tables[i]);        \
     i++;
     FNV_FOR_EACH_TYPE_METRIC(FNV_FILL)
@@ -123,7 +125,7 @@ kernel_fn pick_kernel(int dtype, int metric, int cfg, bool full) { return kernel
 kernel_fn pick_scan_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).scan[cfg][full]; }
 kernel_fn pick_sorted_kernel(int dtype, int metric, int cfg, bool full, bool lds, int B) {
   const KernelTable& t = kernel_table(dtype, metric);
-  return lds ? t.merged0[cfg][full] : B <= WAVE ? t.merged1[cfg][full] : t.merged[cfg][full];
+  return lds ? t.merged0[cfg][full] : B <= WAVE ? t.merged1[cfg][full] : B <= 2 * WAVE ? t.merged2[cfg][full] : t.merged[cfg][full];
 }
 wire_fn pick_wire_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).select[cfg][full]; }
 wire_fn pick_connect_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).connect[cfg][full]; }

@@ -1,7 +1,7 @@
 // kernel_inst.hip -- one compilation = the instantiations of ONE kernel family for ONE (element type, metric):
 //   hipcc -c -DFNV_INST_T=float -DFNV_INST_TAG=f32 -DFNV_INST_METRIC=0 -DFNV_INST_MTAG=l2 -DFNV_INST_FAMILY=4 ...
 // families: 0 exact two-heap kernel + entry scan, 3 wiring kernels, 4 merged beam (<= 256 entries in registers),
-// 5 merged beam (<= 64 entries in registers), 6 merged beam (LDS, any width).  flatnav_amd/build.py compiles the 30 combinations in parallel and links them with beam_search.hip.
+// 5 merged beam (<= 64 entries in registers), 6 merged beam (LDS, any width), 7 merged beam (<= 128 in registers).  flatnav_amd/build.py compiles the 30 combinations in parallel and links them with beam_search.hip.
 #include <hip/hip_runtime.h>
 
 #include "kernel_table.h"
@@ -42,6 +42,9 @@ static void fill_rows(KernelTable& t) {
 #elif FNV_INST_FAMILY == 6
 #define FNV_COMMA_ZERO , 0
   FNV_ROW(t.merged0, beam_search_merged_kernel, FNV_COMMA_ZERO)
+#elif FNV_INST_FAMILY == 7
+#define FNV_COMMA_TWO , 2
+  FNV_ROW(t.merged2, beam_search_merged_kernel, FNV_COMMA_TWO)
 #else
   FNV_ROW(t.select, wire_select_kernel)
   FNV_ROW(t.connect, wire_connect_kernel)
@@ -56,6 +59,8 @@ void FNV_CAT(fill_merged_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 void FNV_CAT(fill_merged1_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 #elif FNV_INST_FAMILY == 6
 void FNV_CAT(fill_merged0_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
+#elif FNV_INST_FAMILY == 7
+void FNV_CAT(fill_merged2_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 #else
 void FNV_CAT(fill_wire_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 #endif

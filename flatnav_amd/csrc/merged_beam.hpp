@@ -5,7 +5,7 @@
 // per entry (bit 31 of the id word) -- instead of the reference's two binary heaps (neighbors: B+1 entries,
 // candidates: every admitted node, 2B+192 slots in the heap kernel), and ONE MERGE PER LINK ROW instead of one
 // insertion per admitted neighbour.  Template parameter R:
-//   R = 4, 1   beams of up to R * 64 entries RESIDENT IN REGISTERS: entry e lives in lane e % 64 of register pair
+//   R = 4, 2, 1  beams of up to R * 64 entries RESIDENT IN REGISTERS: entry e lives in lane e % 64 of register pair
 //              (kr, ir)[e / 64]; entries beyond the beam's size hold {+inf, EMPTY_ID} (whose bit 31 is set, so they
 //              never look unexpanded).  The merge's permutation goes through the LDS array (one scatter, one read
 //              back of the chunks that moved).
