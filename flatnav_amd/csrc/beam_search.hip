@@ -171,7 +171,7 @@ struct fnv_index_s {
   int32_t* d_labels = nullptr;
   int num_cus = 0;
   // options
-  int64_t visited_factor = 27, visited_slots = 0, visited_floor = 2048, occupancy_target = 13, cand_factor = 2,
+  int64_t visited_factor = 27, visited_slots = 0, visited_floor = 2048, occupancy_target = 13, occupancy_roomy = 10, cand_factor = 2,
           cand_slots = 0, spill_entries = 16384, blocks_per_cu = 0, visited_wide = 0,
           entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0, sorted_beam = 2,
           sorted_beam_min = 1, sorted_cand_lds = 2, sorted_tail_exact_pct = -1, beam_registers = 1;
@@ -398,7 +398,7 @@ int fnv_index_view(fnv_index_t src, fnv_index_t* out) {
   v->d_links = src->d_links;
   v->d_labels = src->d_labels;
   v->visited_factor = src->visited_factor; v->visited_slots = src->visited_slots; v->visited_floor = src->visited_floor;
-  v->occupancy_target = src->occupancy_target; v->cand_factor = src->cand_factor; v->cand_slots = src->cand_slots;
+  v->occupancy_target = src->occupancy_target; v->occupancy_roomy = src->occupancy_roomy; v->cand_factor = src->cand_factor; v->cand_slots = src->cand_slots;
   v->spill_entries = src->spill_entries; v->blocks_per_cu = src->blocks_per_cu; v->visited_wide = src->visited_wide;
   v->entry_kernel = src->entry_kernel; v->output_node_ids = src->output_node_ids; v->visited_tag_bits = src->visited_tag_bits;
   v->sorted_beam = src->sorted_beam; v->sorted_beam_min = src->sorted_beam_min;
@@ -524,6 +524,7 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
     ix->visited_slots = value;
   } else if (n == "visited_floor") ix->visited_floor = std::max<int64_t>(256, value);
   else if (n == "occupancy_target") ix->occupancy_target = value;
+  else if (n == "occupancy_roomy") ix->occupancy_roomy = std::max<int64_t>(1, value);
   else if (n == "cand_factor") ix->cand_factor = std::max<int64_t>(1, value);
   else if (n == "cand_slots") ix->cand_slots = value;
   else if (n == "spill_entries") ix->spill_entries = std::max<int64_t>(1, value);
@@ -648,7 +649,10 @@ static int configure_launch(fnv_index_s* ix, SearchParams& p, kernel_fn kern, in
     lds_bytes = lay_out(ix, p, sizes[pick], mode);
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)std::min<uint32_t>(lds_bytes, 160u * 1024u));
-    const int target = (int)ix->occupancy_target;
+    // (a table that holds every id is worth more than the last resident queries: it is kept down to
+    // `occupancy_roomy` of them -- measured with the merged-beam kernel at ef 160-200: -4...-18 % time at 11 resident
+    // queries against a smaller table that overflows at 15; below that the smaller table wins again)
+    const int target = (mode != MODE_HEAPS && resident(lds_bytes) >= (int)ix->occupancy_roomy) ? 0 : (int)ix->occupancy_target;
     const uint32_t roomy_tag16 = p.vis_tag16;
     for (size_t cand = pick; cand-- > 0 && sizes[cand] >= (uint32_t)ix->visited_floor && resident(lds_bytes) < target;) {
       const uint32_t smaller = lay_out(ix, p, sizes[cand], mode);
