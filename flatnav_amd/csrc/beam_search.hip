@@ -624,7 +624,8 @@ static uint32_t lay_out(const fnv_index_s* ix, SearchParams& p, uint32_t slots, 
 // a lone wave issues slowly -- below ~13 resident queries per CU the loss of latency hiding costs more than sending
 // part of the ids to the HBM bitmap (measured: profiles/r1_visited_sizing.md).  So: the largest size <= roomy that
 // still leaves `occupancy_target` queries per CU, but never below visited_floor slots.
-static int configure_launch(fnv_index_s* ix, SearchParams& p, kernel_fn kern, int mode, uint32_t* lds_out, int* bpc_out) {
+static int configure_launch(fnv_index_s* ix, SearchParams& p, kernel_fn kern, int mode, uint32_t* lds_out, int* bpc_out,
+                            bool grow_free = true) {
   auto resident = [&](uint32_t lds) -> int {  // query slots one CU can hold with this much LDS each
     if (lds > 160u * 1024u) return 0;
     int n = 0;
@@ -663,6 +664,20 @@ static int configure_launch(fnv_index_s* ix, SearchParams& p, kernel_fn kern, in
       lds_bytes = smaller;
     }
     lds_bytes = lay_out(ix, p, sizes[pick], mode);
+    // A bigger table that costs no resident query is free: at ef=52 the 2048-slot table (60 % full at the end of a
+    // query) already sends ids to the HBM bitmap; 3072 slots fit the same 16 queries per CU (-7 % kernel time).
+    if (grow_free && pick + 1 == sizes.size()) {
+      for (int step = 0; step < 2; step++) {
+        const uint32_t have = p.vis_slots;
+        const uint32_t next = (have & (have - 1)) == 0 ? have / 2 * 3 : have / 3 * 4;
+        if (next > (1u << 15)) break;
+        SearchParams q = p;
+        const uint32_t bytes = lay_out(ix, q, next, mode);
+        if (q.vis_tag16 != p.vis_tag16 || q.vis_slots != next || bytes > 160u * 1024u || resident(bytes) < resident(lds_bytes)) break;
+        p = q;
+        lds_bytes = bytes;
+      }
+    }
   }
   if (lds_bytes > 160u * 1024u)
     return fail(FNV_ERR_INVALID, "ef_search too large for the on-chip beam state (needs " + std::to_string(lds_bytes) +
@@ -752,14 +767,15 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
       without.cand_slots = 0;
       uint32_t lds_w = 0, lds_wo = 0;
       int bpc_w = 0, bpc_wo = 0;
-      rc = configure_launch(ix, without, plan.skern, plan.mode, &lds_wo, &bpc_wo);
+      rc = configure_launch(ix, without, plan.skern, plan.mode, &lds_wo, &bpc_wo, false);
       if (rc) return rc;
-      const int rc_w = configure_launch(ix, with, plan.skern, plan.mode, &lds_w, &bpc_w);
+      const int rc_w = configure_launch(ix, with, plan.skern, plan.mode, &lds_w, &bpc_w, false);
       const bool keep_lds = rc_w == FNV_OK && (ix->sorted_cand_lds == 1 || (ix->sorted_cand_lds == 2 && bpc_w >= bpc_wo &&
                                                                               with.vis_slots >= without.vis_slots));
-      plan.sorted = keep_lds ? with : without;
-      plan.slds = keep_lds ? lds_w : lds_wo;
-      plan.sbpc = keep_lds ? bpc_w : bpc_wo;
+      plan.sorted = p;
+      plan.sorted.cand_slots = keep_lds ? with.cand_slots : 0u;
+      rc = configure_launch(ix, plan.sorted, plan.skern, plan.mode, &plan.slds, &plan.sbpc);  // + the free table growth
+      if (rc) return rc;
       if (!plan.sorted.vis_tag16) plan.mode = MODE_HEAPS;
       if ((uint64_t)plan.sorted.cand_slots + plan.sorted.spill_entries < 3ull * (uint64_t)B + 256) plan.mode = MODE_HEAPS;
     }
