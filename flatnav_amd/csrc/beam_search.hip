@@ -171,7 +171,7 @@ struct fnv_index_s {
   int32_t* d_labels = nullptr;
   int num_cus = 0;
   // options
-  int64_t visited_factor = 27, visited_slots = 0, visited_floor = 2048, occupancy_target = 13, occupancy_roomy = 10, cand_factor = 2,
+  int64_t visited_factor = 27, visited_slots = 0, visited_floor = 2048, occupancy_target = 13, occupancy_roomy = 9, cand_factor = 2,
           cand_slots = 0, spill_entries = 16384, blocks_per_cu = 0, visited_wide = 0,
           entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0, sorted_beam = 2,
           sorted_beam_min = 1, sorted_cand_lds = 2, sorted_tail_exact_pct = -1, beam_registers = 1;
@@ -651,7 +651,7 @@ static int configure_launch(fnv_index_s* ix, SearchParams& p, kernel_fn kern, in
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)std::min<uint32_t>(lds_bytes, 160u * 1024u));
     // (a table that holds every id is worth more than the last resident queries: it is kept down to
-    // `occupancy_roomy` of them -- measured with the merged-beam kernel at ef 160-200: -4...-18 % time at 11 resident
+    // `occupancy_roomy` (9) of them -- measured with the merged-beam kernel at ef 160-200: -4...-18 % time at 9-11 resident
     // queries against a smaller table that overflows at 15; below that the smaller table wins again)
     const int target = (mode != MODE_HEAPS && resident(lds_bytes) >= (int)ix->occupancy_roomy) ? 0 : (int)ix->occupancy_target;
     const uint32_t roomy_tag16 = p.vis_tag16;

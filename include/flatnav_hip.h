@@ -139,7 +139,7 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *   "visited_factor"  roomy LDS visited-table size = visited_factor * beam width + 600 slots, rounded up to
  *                     2^j or 3*2^j (default 27); used as is while "occupancy_target" queries fit per CU
  *   "occupancy_roomy" the merged-beam kernel keeps the roomy table while at least this many queries stay resident per
- *                     CU (default 10: a table that holds every id beats the last few resident queries)
+ *                     CU (default 9: a table that holds every id beats the last few resident queries)
  *   "occupancy_target" resident queries per CU below which the table is shrunk step by step (ids that
  *                     find both their buckets full go to the per-slot HBM bitmap, results unchanged);
  *                     default 13, 0 = never shrink
