@@ -770,12 +770,29 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
       rc = configure_launch(ix, without, plan.skern, plan.mode, &lds_wo, &bpc_wo, false);
       if (rc) return rc;
       const int rc_w = configure_launch(ix, with, plan.skern, plan.mode, &lds_w, &bpc_w, false);
-      const bool keep_lds = rc_w == FNV_OK && (ix->sorted_cand_lds == 1 || (ix->sorted_cand_lds == 2 && bpc_w >= bpc_wo &&
-                                                                              with.vis_slots >= without.vis_slots));
-      plan.sorted = p;
-      plan.sorted.cand_slots = keep_lds ? with.cand_slots : 0u;
-      rc = configure_launch(ix, plan.sorted, plan.skern, plan.mode, &plan.slds, &plan.sbpc);  // + the free table growth
+      // (an exact re-run whose candidates heap lives in HBM pays a global round trip per heap operation: a handful of
+      // such queries per launch are stragglers that cost 10 % of it -- measured at ef=100 on float data with 5 re-runs
+      // in 10 000 queries -- so up to beams of 128 the LDS home is worth going down to 9 resident queries; wider beams'
+      // heaps cost more LDS than the stragglers cost time)
+      bool keep_lds = rc_w == FNV_OK && (ix->sorted_cand_lds == 1 ||
+                                         (ix->sorted_cand_lds == 2 && ((bpc_w >= bpc_wo && with.vis_slots >= without.vis_slots) ||
+                                                                       (B <= 2 * WAVE && p.row_bytes >= 256 && bpc_w >= (int)ix->occupancy_roomy))));
+      // both candidates once more with the free table growth; an LDS home that costs residency AND table slots is not taken
+      SearchParams fin_w = p, fin_wo = p;
+      fin_w.cand_slots = with.cand_slots;
+      fin_wo.cand_slots = 0u;
+      uint32_t flds_w = 0, flds_wo = 0;
+      int fbpc_w = 0, fbpc_wo = 0;
+      rc = configure_launch(ix, fin_wo, plan.skern, plan.mode, &flds_wo, &fbpc_wo);
       if (rc) return rc;
+      if (keep_lds) {
+        rc = configure_launch(ix, fin_w, plan.skern, plan.mode, &flds_w, &fbpc_w);
+        if (rc) return rc;
+        if (ix->sorted_cand_lds == 2 && fin_w.vis_slots < fin_wo.vis_slots && fbpc_w < fbpc_wo) keep_lds = false;
+      }
+      plan.sorted = keep_lds ? fin_w : fin_wo;
+      plan.slds = keep_lds ? flds_w : flds_wo;
+      plan.sbpc = keep_lds ? fbpc_w : fbpc_wo;
       if (!plan.sorted.vis_tag16) plan.mode = MODE_HEAPS;
       if ((uint64_t)plan.sorted.cand_slots + plan.sorted.spill_entries < 3ull * (uint64_t)B + 256) plan.mode = MODE_HEAPS;
     }

@@ -171,8 +171,9 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *                     permutation goes through LDS); 0 = the array always lives in LDS, as it does for wider beams
  *   "sorted_beam_min" smallest beam width the merged-beam kernel is used for (default 1)
  *   "sorted_cand_lds" where the exact re-run of the merged-beam kernel keeps its candidates heap: 2 (default) = in LDS
- *                     when that costs neither resident queries nor visited-table slots, else in the slot's HBM spill
- *                     area; 0 = always HBM, 1 = always LDS (tests)
+ *                     when that costs neither resident queries nor visited-table slots, or -- beams of at most 128
+ *                     entries -- leaves "occupancy_roomy" resident queries; else in the slot's HBM spill area;
+ *                     0 = always HBM, 1 = always LDS (tests)
  *   "entry_kernel"    1 = entry points of the whole batch come from the LDS-staged entry_scan_kernel (K0);
  *                     0 (default) = every query scans them inside the search kernel.  Same results bit for
  *                     bit; measured equally fast on MI355X (the shared scan rows are L2 hits either way)
