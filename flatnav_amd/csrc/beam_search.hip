@@ -776,7 +776,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
       // heaps cost more LDS than the stragglers cost time)
       bool keep_lds = rc_w == FNV_OK && (ix->sorted_cand_lds == 1 ||
                                          (ix->sorted_cand_lds == 2 && ((bpc_w >= bpc_wo && with.vis_slots >= without.vis_slots) ||
-                                                                       (B <= 2 * WAVE && p.row_bytes >= 256 && bpc_w >= (int)ix->occupancy_roomy))));
+                                                                       (B <= 2 * WAVE && bpc_w >= (int)ix->occupancy_roomy))));
       // both candidates once more with the free table growth; an LDS home that costs residency AND table slots is not taken
       SearchParams fin_w = p, fin_wo = p;
       fin_w.cand_slots = with.cand_slots;
