@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- QPS of the batched flat-NSW k-NN search on MI355X, one line per BASELINE.json configuration.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c3-lowrank|c4|c5] [--index-size n ...]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c3-lowrank|c4|c5|c5-lowrank]
+                  [--secondary-configs c4,c3-lowrank,c5,c5-lowrank | none] [--index-size n ...]
 
 One "step" = one pass of the hot path over one batch: `nq` queries (10 000) searched against an index resident in
 HBM; queries and result buffers are in HBM when the timed region starts; every step searches a DIFFERENT batch.
@@ -10,13 +11,21 @@ Configurations (BASELINE.json `configs`, generators of SURVEY.md 8d; no dataset 
   c3            10M x 768 randn, rows normalised, inner product ("angular")        ef=200 as worded (recall is hopeless)
   c3-lowrank    10M x 768 S3 low-rank unit vectors, inner product                  ef by the recall rule
   c4            GloVe-1.2M stand-in: 1 183 514 x 100 low-rank unit vectors, IP     ef sweep 50..400, value at the recall rule
-  c5            50M x 128 randn, L2, index replicated per GPU, queries sharded     ef=100
+  c5            50M x 128 randn, L2, index replicated per GPU, queries sharded     ef=100 as worded (recall is hopeless)
+  c5-lowrank    50M x 128 S1 generator (the SIFT stand-in at N=50M), L2            ef by the recall rule
 All with M=32, ef_construction=100, K=10.  The metric's rule: the smallest ef of the sweep with recall@10 >= 0.95,
 recall measured on all 10 000 queries of the first batch against exact brute force.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel; achieved =
-algorithmic bytes per launch / average launch duration from HIP events on the launch stream), `cpu_baseline` (N=1:
-the CPU oracle timed on the host cores), `secondary` (fixed-ef lines) and `sustained` (>= 1 s of back-to-back steps).
+algorithmic bytes per launch / average launch duration from HIP events on the launch stream; `gather_ceiling` = what a
+pure random-row gather of this very vector table reaches, measured in the run), `cpu_baseline` (N=1: the CPU oracle
+timed on the host cores), `secondary` (fixed-ef lines of the main configuration + one summary per further configuration)
+and `sustained` (>= 1 s of back-to-back steps).  The value, metric and config of the line are the main configuration's
+(c2 by default).  FURTHER CONFIGURATIONS -- like the reference's harness, which runs a list of datasets and ef values in
+one invocation (experiments/run-benchmark.py:362-506, tools/query_npy.cpp:132-158) -- run after it in the same process
+and land as full entries (own recall / ef rule, roofline, counters, cpu_baseline with GPU ids == CPU ids) under the
+top-level keys "c4", "c3-lowrank", "c5", "c5-lowrank" (N = 1; with N > 1 GPUs only "c5", the configuration that is
+worded for 8 GPUs); `--secondary-configs none` turns them off, `--time-budget` skips what no longer fits.
 Multi-GPU: one process per GPU; `--gpus N` without a torch.distributed environment spawns the N ranks itself.
 Index replicated with one RCCL broadcast per buffer at load, queries sharded, no per-query collective; weak scaling.
 """
@@ -38,7 +47,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-HBM_ACHIEVABLE_GBPS = 6300.0  # what a streaming float4 copy reaches on this part (same guide)
+INFINITY_CACHE_BYTES = 256 << 20  # die-level L3 (same guide): part of a small index is served from it, and FETCH_SIZE counts those hits
 
 CONFIGS = {
     # name: generator, n, dim, metric, dtype, fixed ef (0 = recall rule), sweep, fixed-ef secondary lines
@@ -50,11 +59,16 @@ CONFIGS = {
     "c3-lowrank": dict(gen="lowrank_unit", n=10_000_000, dim=768, metric="angular", ef=0,
                        sweep=[100, 200, 300, 400, 600, 800, 1000, 1200, 1600], secondary=[200],
                        title="C3 recall-qualified variant (S3 low-rank unit vectors, SURVEY.md 8d)"),
-    "c4": dict(gen="glove_like", n=1_183_514, dim=100, metric="angular", ef=0, sweep=[50, 100, 200, 400],
+    "c4": dict(gen="glove_like", n=1_183_514, dim=100, metric="angular", ef=0,
+               sweep=[50, 64, 80, 100, 110, 120, 140, 170, 200, 400],
                secondary=[50, 100, 200, 400], title="GloVe-1.2M stand-in (rank-24 low-rank unit vectors, SURVEY.md 8d)"),
     "c5": dict(gen="randn", n=50_000_000, dim=128, metric="l2", ef=100, sweep=[], secondary=[],
-               title="C5: randn, index replicated per GPU, queries sharded"),
+               title="C5 as worded: randn, index replicated per GPU, queries sharded"),
+    "c5-lowrank": dict(gen="sift_like", n=50_000_000, dim=128, metric="l2", ef=0,
+                       sweep=[50, 64, 80, 100, 128, 160, 200, 300, 400, 600], secondary=[],
+                       title="C5 recall-qualified variant (the S1 SIFT stand-in generator at N=50M, SURVEY.md 8d)"),
 }
+SECONDARY_DEFAULT = {1: "c4,c3-lowrank,c5,c5-lowrank"}  # world size -> configurations after the main one (else: "c5")
 
 
 def log(*a):
@@ -92,6 +106,13 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--sustain-seconds", type=float, default=1.0)
     ap.add_argument("--opt", action="append", default=[], help="C-ABI option name=value")
+    ap.add_argument("--secondary-configs", default="default",
+                    help="comma-separated configurations to run after the main one, each a full entry under its own "
+                         "top-level key (default: c4,c3-lowrank,c5,c5-lowrank on one GPU, c5 on several; 'none' = off)")
+    ap.add_argument("--secondary-index-size", type=int, default=0,
+                    help="node count of the secondary configurations (0 = each configuration's own; tests use small ones)")
+    ap.add_argument("--time-budget", type=float, default=1500.0,
+                    help="seconds after which no further secondary configuration is started")
     return ap.parse_args()
 
 
@@ -166,8 +187,17 @@ class Data:
         return self.Q
 
 
+class Ctx:
+    """What every configuration of one invocation shares: torch, the process group, this rank's GPU."""
+
+    def __init__(self, torch, dist, rank, world, local_rank, dev_t, hw, t_start):
+        self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
+        self.local_rank, self.dev_t, self.hw, self.t_start = local_rank, dev_t, hw, t_start
+
+
 def main() -> None:
     args = parse_args()
+    t_start = time.time()
     # ---- N > 1 without a torch.distributed environment: spawn the ranks (before anything touches the GPU) -------
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
@@ -197,11 +227,64 @@ def main() -> None:
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    import flatnav_amd as flatnav
     from flatnav_amd import datasets as ds
+
+    hw = ds.effective_cpus()  # honours the cgroup CPU quota (16 on the MI355X boxes, 256 CPUs visible)
+    ctx = Ctx(torch, dist, rank, world, local_rank, torch.device("cuda", local_rank), hw, t_start)
+
+    out = run_config(ctx, args, args.config, main_line=True)
+
+    # ---- further configurations, each a full entry under its own key (module docstring) ---------------------------
+    names = args.secondary_configs
+    if names == "default":
+        names = SECONDARY_DEFAULT.get(world, "c5")
+        if args.n or args.ef >= 0 or args.dtype != "float32" or args.no_secondary or args.opt:  # a reduced / special run is about its one configuration
+            names = "none"
+    names = [] if names in ("none", "") else [n for n in names.split(",") if n and n != args.config]
+    for name in names:
+        if name not in CONFIGS:
+            raise SystemExit("unknown configuration in --secondary-configs: %s" % name)
+        # every rank must take the same decision: rank 0's clock decides
+        go = (time.time() - t_start) < args.time_budget
+        if dist is not None:
+            flag = torch.tensor([1 if go else 0], device=ctx.dev_t)
+            dist.broadcast(flag, src=0)
+            go = bool(flag.item())
+        if not go:
+            if rank == 0:
+                out[name] = {"skipped": "time budget of %.0f s used up (%.0f s elapsed)" % (args.time_budget, time.time() - t_start)}
+                out["secondary"].append({"config": name, "skipped": True})
+            continue
+        sub = argparse.Namespace(**vars(args))
+        sub.n, sub.ef, sub.ef_sweep, sub.opt = args.secondary_index_size, -1, "", list(args.opt)
+        sub.steps, sub.warmup = max(3, min(args.steps, 10)), max(1, min(args.warmup, 3))
+        sub.sustain_seconds = 0.0
+        t0 = time.time()
+        entry = run_config(ctx, sub, name, main_line=False)
+        if rank == 0:
+            entry["wall_seconds"] = round(time.time() - t0, 1)
+            out[name] = entry
+            out["secondary"].append({"config": name, "value": entry["value"], "unit": entry["unit"],
+                                     "ef_search": entry["config"]["ef_search"], "recall_at_10": entry["config"]["recall_at_10"],
+                                     "roofline_frac": entry["roofline"]["frac"], "full_entry": "top-level key \"%s\"" % name})
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        out["bench_wall_seconds"] = round(time.time() - t_start, 1)
+        print(json.dumps(out), flush=True)
+
+
+def run_config(ctx, args, config, main_line):
+    """Builds the index of one configuration, selects ef, times `args.steps` launches and returns (rank 0) the JSON
+    object of that configuration -- the contract line when `main_line`, else a full entry of the same shape."""
+    import gc
+
+    import flatnav_amd as flatnav
     from flatnav_amd import hip
 
-    cfg = dict(CONFIGS[args.config])
+    torch, dist, rank, world, local_rank, dev_t, hw = ctx.torch, ctx.dist, ctx.rank, ctx.world, ctx.local_rank, ctx.dev_t, ctx.hw
+    cfg = dict(CONFIGS[config])
     N = args.n or cfg["n"]
     NQ, DIM, M, K = args.nq, cfg["dim"], args.M, args.K
     metric = cfg["metric"]
@@ -209,14 +292,12 @@ def main() -> None:
     if DT == "uint8" and cfg["gen"] != "sift_like":
         raise SystemExit("--dtype uint8 needs the integer-valued c2 data")
     ESIZE = 4 if DT == "float32" else 1
-    hw = ds.effective_cpus()  # honours the cgroup CPU quota (16 on the MI355X boxes, 256 CPUs visible)
-    dev_t = torch.device("cuda", local_rank)
 
     # ---- data: `nb` distinct query batches per rank (one per step, reused cyclically beyond 32) -------------------
     nb = max(1, min(args.steps, 32))
     t0 = time.time()
     data = Data(cfg, N, NQ * nb * world, torch, dev_t)
-    log("[rank %d] data %.1fs (%s)" % (rank, time.time() - t0, data.note))
+    log("[rank %d] %s: data %.1fs (%s)" % (rank, config, time.time() - t0, data.note))
 
     # ---- index: rank 0 builds, the other ranks receive it by RCCL broadcast --------------------------------------
     index = None
@@ -252,6 +333,10 @@ def main() -> None:
     for o in args.opt:
         k, v = o.split("=")
         dev.set_option(k, int(v))
+    ROW = dev.row_bytes  # bytes one row occupies in HBM (>= DIM * ESIZE: 16-byte chunks, whole 128-byte lines when cheap)
+    # bytes of the 128-byte lines one row touches: the stride itself when rows are whole lines, else the expectation for
+    # a row that starts at a random 16-byte boundary inside a line
+    LINE_ROW = ROW if ROW % 128 == 0 else ROW + 112
 
     # ---- device-resident inputs / outputs -----------------------------------------------------------------------
     Q_all = data.queries()
@@ -306,24 +391,24 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    settled = set()
+    tuned = {}
 
     def run(ef, steps, warmup, min_seconds=0.0):
         """Times `steps` launches (batch i mod nb each); returns (elapsed, kernel_ms list, steps done)."""
         def step(i):
             dev.search_device(dq[i % nb].data_ptr(), NQ, K, ef, 100, d_dist.data_ptr(), d_lab.data_ptr(),
                               d_cnt.data_ptr(), d_nd.data_ptr(), d_nh.data_ptr(), stream=stream.cuda_stream)
-        if ef not in settled:  # the library's per-beam-width kernel choice: three timed samples of each of its (up to
-            settled.add(ef)    # five) variants, harvested by the following call -- set-up, like a JIT's first calls
-            for i in range(17):
-                step(i)
-                torch.cuda.synchronize()
+        if ef not in tuned:  # the library's per-beam-width kernel choice, settled in ONE explicit call (fnv_tune) on batch
+            t0 = time.perf_counter()  # 0 -- set-up like a JIT's compilation, outside every timed region
+            dev.tune(int(dq[0].data_ptr()), K, ef, 100, nq=NQ)
+            tuned[ef] = time.perf_counter() - t0
         for i in range(warmup):
             step(i)
             torch.cuda.synchronize()  # untimed
         barrier()
         dev.status()
         evs = []
+        explored = 0
         barrier()
         t0 = time.perf_counter()
         i = 0
@@ -334,6 +419,7 @@ def main() -> None:
                 step(i)
                 b.record(stream)
                 evs.append((a, b))
+                explored += 1 if dev.launch_info()["exploratory"] else 0
                 i += 1
             if min_seconds <= 0:
                 break
@@ -347,46 +433,49 @@ def main() -> None:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        return elapsed, [a.elapsed_time(b) for a, b in evs], i
+        return elapsed, [a.elapsed_time(b) for a, b in evs], i, explored
 
     step_nodes = max(1, N // 100)
     n_scan = (N + step_nodes - 1) // step_nodes
 
     def launch_bytes(ef, batches):
         """Algorithmic HBM bytes of one launch, averaged over the given batches, from the kernel's own
-        per-query counters; also mean evaluations / hops per query and the recall of batch 0 when it is among them."""
-        tot, nds, nhs = 0, [], []
+        per-query counters; also the bytes of the 128-byte lines those rows touch (LINE_ROW each), mean evaluations / hops."""
+        tot, tot_rows, nds, nhs = 0, 0, [], []
         for b in batches:
             dev.search_device(dq[b].data_ptr(), NQ, K, ef, 100, d_dist.data_ptr(), d_lab.data_ptr(), d_cnt.data_ptr(),
                               d_nd.data_ptr(), d_nh.data_ptr(), stream=stream.cuda_stream)
             torch.cuda.synchronize()
             nd, nh = d_nd.cpu().numpy().astype(np.int64), d_nh.cpu().numpy().astype(np.int64)
             tot += int(((n_scan + nd) * DIM * ESIZE + nh * M * 4 + K * 4).sum())
+            tot_rows += int(((n_scan + nd) * LINE_ROW + nh * M * 4 + K * 4).sum())
             nds.append(nd.mean())
             nhs.append(nh.mean())
-        return tot / len(batches), float(np.mean(nds)), float(np.mean(nhs))
+        return tot / len(batches), tot_rows / len(batches), float(np.mean(nds)), float(np.mean(nhs))
 
     def measure(ef, steps, warmup, min_seconds=0.0):
-        elapsed, kms, done = run(ef, steps, warmup, min_seconds)
+        elapsed, kms, done, explored = run(ef, steps, warmup, min_seconds)
         used = sorted(set(i % nb for i in range(done)))
-        byts, nd_mean, nh_mean = launch_bytes(ef, used[:8])
+        byts, row_byts, nd_mean, nh_mean = launch_bytes(ef, used[:8])
         avg_kernel_s = float(np.mean(kms)) / 1e3
-        return dict(elapsed=elapsed, steps=done, qps=NQ * world * done / elapsed, bytes=byts, nd=nd_mean, nh=nh_mean,
-                    kernel_ms=avg_kernel_s * 1e3, achieved=byts / avg_kernel_s / 1e9)
+        return dict(elapsed=elapsed, steps=done, qps=NQ * world * done / elapsed, bytes=byts, row_bytes=row_byts, nd=nd_mean,
+                    nh=nh_mean, kernel_ms=avg_kernel_s * 1e3, achieved=byts / avg_kernel_s / 1e9, explored=explored)
 
     main_m = measure(EF, args.steps, args.warmup)
     out = None
     if rank == 0:
         recall = recall_at(EF)
         geom = dev.launch_geometry()
+        info = dev.launch_info()
         replay = dev.replayed_queries()
+        ceiling = dev.gather_ceiling(geom["blocks_per_cu"])  # a pure gather of this very table, same load pattern
         # informational: the host-buffer entry point (pageable H2D of the queries + kernel + D2H of results)
         t0 = time.perf_counter()
         for i in range(3):
             dev.search(Q_rank[i % nb], K, EF)
         host_qps = 3 * NQ / (time.perf_counter() - t0)
         log("[rank 0] host-buffer (PCIe-inclusive) path: %.0f queries/s" % host_qps)
-    # ---- secondary lines (all ranks take part: the timing barrier is collective) -----------------------------------
+    # ---- fixed-ef lines of this configuration (all ranks take part: the timing barrier is collective) ----------------
     secondary = []
     sustained = None
     if not args.no_secondary:
@@ -397,7 +486,7 @@ def main() -> None:
                          "note": ">= %.1f s of back-to-back steps over %d rotating query batches (the contract line "
                                  "above times exactly --steps launches)" % (args.sustain_seconds, nb)}
         for ef2 in cfg["secondary"]:
-            m2 = measure(ef2, max(5, min(args.steps, 20)), 5)
+            m2 = measure(ef2, max(5, min(args.steps, 20)), min(5, args.warmup))
             rec2 = recall_at(ef2) if rank == 0 else None
             secondary.append({"ef_search": ef2, "value": m2["qps"], "unit": "queries/s",
                               "recall_at_10": None if rec2 is None else round(rec2, 4),
@@ -408,6 +497,7 @@ def main() -> None:
         kname = {"two_heaps": "fnv_dev::beam_search_kernel",
                  "merged_beam_registers": "fnv_dev::beam_search_merged_kernel",
                  "merged_beam_lds": "fnv_dev::beam_search_merged_kernel"}[geom["kernel"]]
+        index_bytes = N * (ROW + 4 * M + 4)
         out = {
             "metric": "qps_at_recall10_ge_0.95",
             "value": main_m["qps"],
@@ -424,7 +514,7 @@ def main() -> None:
             "config": {
                 "workload": "%s [%s]: %d x %d %s %s, M=%d, ef_construction=%d, ef_search=%d, K=%d, %d batched queries "
                             "per GPU per step (a different batch every step), index in HBM"
-                            % (args.config, cfg["title"], N, DIM, DT, "L2" if metric == "l2" else "inner product", M,
+                            % (config, cfg["title"], N, DIM, DT, "L2" if metric == "l2" else "inner product", M,
                                args.efc, EF, K, NQ),
                 "recall_at_10": round(recall, 4),
                 "recall_queries": NQ,
@@ -438,11 +528,17 @@ def main() -> None:
                 "mean_dist_evals_per_query": main_m["nd"],
                 "mean_hops_per_query": main_m["nh"],
                 "launch": geom,
+                "kernel_variant": info["variant"],
+                "kernel_choice": "fnv_tune: every variant measured on batch 0 in one explicit call before the warm-up "
+                                 "(%.3f s); timed launches that were exploratory samples of the adaptive choice: %d"
+                                 % (tuned.get(EF, 0.0), main_m["explored"]),
                 "queries_replayed_by_exact_kernel": replay["total"],
                 "host_buffer_qps_pcie_inclusive": round(host_qps),
-                "measured_in_this_run": "value, ms_per_step, recall, roofline.achieved/avg_kernel_ms, counters, "
-                                        "secondary, sustained, cpu_baseline; roofline.traffic is null (PMC passes are "
-                                        "separate rocprofv3 runs: see profiles/)",
+                "index_bytes_in_hbm": index_bytes,
+                "index_fraction_in_infinity_cache": round(min(1.0, INFINITY_CACHE_BYTES / index_bytes), 3),
+                "measured_in_this_run": "value, ms_per_step, recall, roofline.achieved/avg_kernel_ms, gather ceiling, "
+                                        "counters, secondary, sustained, cpu_baseline; roofline.traffic is null (PMC "
+                                        "passes are separate rocprofv3 runs: see profiles/)",
             },
             "roofline": {
                 "bound": "hbm",
@@ -451,24 +547,36 @@ def main() -> None:
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": main_m["achieved"] / HBM_PEAK_GBPS,
-                "frac_of_achievable": main_m["achieved"] / HBM_ACHIEVABLE_GBPS,
+                "gather_ceiling": ceiling,
+                "frac_of_gather_ceiling": main_m["achieved"] / ceiling,
+                "gather_ceiling_note": "fnv_gather_ceiling, measured in this run: GB/s of algorithmic row bytes that a pure "
+                                       "gather of random rows of THIS vector table (%d-byte rows at a %d-byte stride, "
+                                       "%.2f GB) reaches with the search kernel's load pattern at %d waves per CU and no "
+                                       "other work" % (DIM * ESIZE, ROW, N * ROW / 1e9, geom["blocks_per_cu"]),
                 "traffic": None,
-                "traffic_recorded": recorded_traffic(args.config, DT, N, NQ, EF),
+                "traffic_recorded": recorded_traffic(config, DT, N, NQ, EF),
                 "algorithmic_bytes_per_launch": main_m["bytes"],
+                "row_bytes": DIM * ESIZE,
+                "row_stride_bytes": ROW,
+                "line_bytes_per_launch": main_m["row_bytes"],
+                "achieved_line_GBps": main_m["row_bytes"] / (main_m["kernel_ms"] / 1e3) / 1e9,
                 "avg_kernel_ms": main_m["kernel_ms"],
             },
             "secondary": secondary,
             "sustained": sustained,
         }
+        if not main_line:
+            for k in ("sustained",):
+                out.pop(k)
+            out["ef_lines"] = out.pop("secondary")
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(index, dev, Q_rank[0], K, EF, hw, DT, metric)
-        dev.close()
-        del index
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+            out["cpu_baseline"] = cpu_baseline(index, dev, Q_rank[0], K, EF, hw, DT, metric, seconds=8.0 if main_line else 5.0)
+    # ---- give everything back before the next configuration ----------------------------------------------------------
+    dev.close()
+    del dev, index, dq, d_dist, d_lab, d_cnt, d_nd, d_nh, gt, data, Q_all, Q_rank
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
 
 
 def exact_topk(torch, dev, q, K, N, DIM, DT, metric, block=250_000):
@@ -513,7 +621,7 @@ def recorded_traffic(config, dtype, n, nq, ef):
     """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate runs, corrected as MI355X_MICROARCH.md prescribes) -- a RECORDED number, labelled as such; None unless
     the committed passes profiled this very workload."""
-    for name in ("r2_pmc_hbm_traffic.json", "pmc_hbm_traffic.json"):
+    for name in ("r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "pmc_hbm_traffic.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
@@ -525,7 +633,7 @@ def recorded_traffic(config, dtype, n, nq, ef):
     return None
 
 
-def cpu_baseline(index, dev, Q, K, EF, hw, dtype, metric):
+def cpu_baseline(index, dev, Q, K, EF, hw, dtype, metric, seconds=8.0):
     """The CPU oracle (restated reference search, oracle/) on the same graph and a bounded sample of the same queries,
     all usable host threads, roughly 10-20 s.  Also re-checks GPU == CPU ids on the sample."""
     from oracle import oracle as orc
@@ -541,10 +649,10 @@ def cpu_baseline(index, dev, Q, K, EF, hw, dtype, metric):
     t0 = time.perf_counter()
     o.search(Q[:256], K, EF, threads=threads)  # warm; also sizes the sample
     per_q = (time.perf_counter() - t0) / 256
-    sample = int(min(len(Q), max(256, 4.0 / max(per_q, 1e-9))))
+    sample = int(min(len(Q), max(256, seconds / 2 / max(per_q, 1e-9))))
     reps, t_used, nq_done = 0, 0.0, 0
     ol = None
-    while t_used < 8.0 and reps < 50:
+    while t_used < seconds and reps < 50:
         t0 = time.perf_counter()
         _, ol = o.search(Q[:sample], K, EF, threads=threads)
         t_used += time.perf_counter() - t0

@@ -50,7 +50,9 @@ def _stale(obj, src):
     if not os.path.exists(obj):
         return True
     t = os.path.getmtime(obj)
-    return any(os.path.getmtime(d) > t for d in [src] + HEADERS)
+    # relayout.hpp (upload / measurement kernels) is included by beam_search.hip only
+    deps = HEADERS if src == MAIN else [h for h in HEADERS if not h.endswith("relayout.hpp")]
+    return any(os.path.getmtime(d) > t for d in [src] + deps)
 
 
 def needs_build() -> bool:

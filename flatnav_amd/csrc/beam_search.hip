@@ -32,6 +32,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <limits>
 #include <map>
 #include <mutex>
@@ -68,6 +71,44 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 size_t dtype_size(int dt) { return dt == FNV_DTYPE_FLOAT32 ? 4 : (dt == FNV_DTYPE_UINT8 || dt == FNV_DTYPE_INT8) ? 1 : 0; }
+
+// Every entry point works on its index's device and gives the calling thread its current device back on every exit
+// path: a library call must not move a torch (or any other HIP) caller's allocations to another GPU.
+struct DeviceScope {
+  int prev = -1;
+  bool moved = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceScope(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) {
+      err = hipSetDevice(device);
+      moved = err == hipSuccess;
+    }
+  }
+  ~DeviceScope() {
+    if (moved && prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
+#define ON_DEVICE(dev)                  \
+  DeviceScope device_scope_(dev);       \
+  HIP_TRY(device_scope_.err)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is global per (kernel, device) while several handles (views, replicas on
+// one device) launch concurrently with different beam widths: the limit is only ever RAISED, under one process-wide
+// mutex -- set(A), set(B < A), launch(A) cannot happen.  (A larger limit than a launch needs costs nothing: residency
+// follows the bytes the launch asks for.)
+hipError_t raise_lds_limit(const void* kern, int device, uint32_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, uint32_t> limit;
+  std::lock_guard<std::mutex> lock(mu);
+  uint32_t& have = limit[{device, kern}];
+  if (bytes <= have) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) have = bytes;
+  return e;
+}
 
 // ---- kernel lookup ----------------------------------------------------------------------------------------------
 #ifdef FNV_DEV_FAST_BUILD
@@ -159,8 +200,20 @@ struct PinnedCall {
   uint64_t *out_ndist = nullptr, *out_nhops = nullptr;
 };
 
-struct fnv_index_s {
+// Everything fnv_set_option can change: one block, so that views and replicas start as exact copies of their source.
+struct IndexOptions {
+  int64_t visited_factor = 27, visited_slots = 0, visited_floor = 2048, occupancy_target = 13, occupancy_roomy = 9, cand_factor = 2,
+          cand_slots = 0, spill_entries = 16384, blocks_per_cu = 0, visited_wide = 0,
+          entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0, sorted_beam = 2,
+          sorted_beam_min = 1, sorted_cand_lds = 2, sorted_tail_exact_pct = -1, beam_registers = 1,
+          sorted_variant = -1;
+  int64_t overflow_list = -1;  // -1: automatic (a list in HBM only when the bitmap is larger than 512 KB)
+};
+
+struct fnv_index_s : IndexOptions {
   bool owns_buffers = true;  // false: a view (fnv_index_view) of another handle's vectors / links / labels
+  fnv_index_s* parent = nullptr;  // a view's source: its live node count is read at every launch
+  std::atomic<int> n_views{0};    // live views of this handle's buffers (it cannot be freed before them)
   int device = 0;
   int dtype = FNV_DTYPE_FLOAT32, metric = FNV_METRIC_L2;
   uint32_t M = 0, dim = 0, row_bytes = 0;
@@ -170,11 +223,6 @@ struct fnv_index_s {
   uint32_t* d_links = nullptr;
   int32_t* d_labels = nullptr;
   int num_cus = 0;
-  // options
-  int64_t visited_factor = 27, visited_slots = 0, visited_floor = 2048, occupancy_target = 13, occupancy_roomy = 9, cand_factor = 2,
-          cand_slots = 0, spill_entries = 16384, blocks_per_cu = 0, visited_wide = 0,
-          entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0, sorted_beam = 2,
-          sorted_beam_min = 1, sorted_cand_lds = 2, sorted_tail_exact_pct = -1, beam_registers = 1;
   uint64_t options_version = 0;
   LaunchPlan plan;
   // adaptive kernel choice ("sorted_beam" = 2): per beam width, the best time per query seen for each variant
@@ -186,8 +234,11 @@ struct fnv_index_s {
   };
   std::map<int, Tuner> tuner;
   int sample_B = 0, sample_kernel = -1;  // the launch between ev0 / ev1 is a sample for this entry (-1: it is not)
+  int force_variant = -1;                // fnv_tune: the variant the next launch must run (-1: none)
   uint64_t sample_nq = 0;
-  int64_t overflow_list = -1;  // -1: automatic (a list in HBM only when the bitmap is larger than 512 KB)
+  int last_variant = 0;          // what the most recent launch ran: 0 two-heap kernel, 1 merged beam, 2-4 with exact tail
+  bool last_exploratory = false;  // ... and whether the adaptive choice was still sampling (not its final pick)
+  uint64_t t_enqueue_ns = 0, t_complete_ns = 0;  // host-buffer searches: steady-clock time of launch / of completion
   // workspace (grown on demand)
   uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status, [3] queries a merged-beam launch searched exactly, [4..7] by reason
   unsigned long long* d_phase = nullptr;  // profiling builds only
@@ -248,12 +299,26 @@ int validate_geometry(uint32_t M, uint64_t n_nodes, int data_type, int metric, u
   return FNV_OK;
 }
 
-int alloc_buffers(fnv_index_s* ix) {
-  HIP_TRY(hipSetDevice(ix->device));
+int alloc_buffers(fnv_index_s* ix) {  // the caller is on ix->device
   HIP_TRY(hipMalloc(&ix->d_vectors, ix->capacity * (uint64_t)ix->row_bytes));
   HIP_TRY(hipMalloc(&ix->d_links, ix->capacity * (uint64_t)ix->M * 4));
   HIP_TRY(hipMalloc(&ix->d_labels, ix->capacity * 4));
   return index_common_init(ix);
+}
+
+// Row stride of the vector table.  Rows are 16-byte chunks; when rounding the stride up to whole 128-byte lines costs
+// at most FLATNAV_ROW_PAD_PCT (default 30) per cent of padding it is done: a 100-d float32 row (400 bytes) at a
+// 16-byte stride straddles 4-5 lines (4.0 on average = the 512 bytes the padded row occupies anyway), takes the clamped
+// non-FULL distance path and costs the gather ~20 % of its rate (tools/gather_bench.hip: 5.9 vs 7.1 TB/s of row bytes);
+// at a 512-byte stride it is exactly four lines and whole 8-lane x 4-chunk spans.  The padding is zero in rows and in
+// the staged query, so every distance keeps its bits (zeros add nothing to either partial sum).
+uint32_t row_stride_bytes(uint32_t dim, int data_type) {
+  const uint64_t rb16 = ((uint64_t)dim * dtype_size(data_type) + 15) / 16 * 16;
+  const uint64_t rb128 = (rb16 + 127) / 128 * 128;
+  long pct = 30;
+  if (const char* env = getenv("FLATNAV_ROW_PAD_PCT")) pct = strtol(env, nullptr, 10);
+  if (pct > 0 && (rb128 - rb16) * 100 <= (uint64_t)pct * rb16) return (uint32_t)rb128;
+  return (uint32_t)rb16;
 }
 
 uint32_t pow2_ceil(uint64_t v) {
@@ -266,7 +331,7 @@ uint32_t pow2_ceil(uint64_t v) {
 // SoA device buffers, 256 MB at a time.  Link ids >= id_limit are flagged (and replaced by a self-loop).
 int write_nodes_impl(fnv_index_s* ix, uint64_t first_node, uint64_t count_nodes, const void* aos_rows,
                      uint64_t node_size, uint64_t data_size, uint64_t id_limit, int* bad_out) {
-  HIP_TRY(hipSetDevice(ix->device));
+  ON_DEVICE(ix->device);
   const uint64_t chunk_nodes = std::max<uint64_t>(1, (256ull << 20) / node_size);
   // staging area: [chunk of AoS records][bad flag]; kept on the index (a device build writes dozens of batches)
   const size_t need = std::min(chunk_nodes, count_nodes) * node_size + 16;
@@ -315,7 +380,7 @@ int write_nodes_impl(fnv_index_s* ix, uint64_t first_node, uint64_t count_nodes,
 extern "C" {
 
 const char* fnv_last_error(void) { return g_err.c_str(); }
-const char* fnv_version(void) { return "flatnav_hip gfx950 r2"; }
+const char* fnv_version(void) { return "flatnav_hip gfx950 r3"; }
 
 int fnv_device_count(int* count) {
   if (!count) return fail(FNV_ERR_INVALID, "count is null");
@@ -334,6 +399,7 @@ int fnv_index_alloc(uint32_t M, uint64_t n_nodes, int data_type, int metric, uin
   if (!out) return fail(FNV_ERR_INVALID, "out is null");
   int rc = validate_geometry(M, n_nodes, data_type, metric, dim);
   if (rc) return rc;
+  ON_DEVICE(device);
   fnv_index_s* ix = new fnv_index_s();
   ix->device = device;
   ix->dtype = data_type;
@@ -342,7 +408,7 @@ int fnv_index_alloc(uint32_t M, uint64_t n_nodes, int data_type, int metric, uin
   ix->dim = dim;
   ix->n_nodes = n_nodes;
   ix->capacity = n_nodes;
-  ix->row_bytes = (uint32_t)((dim * dtype_size(data_type) + 15) / 16 * 16);
+  ix->row_bytes = row_stride_bytes(dim, data_type);
   rc = alloc_buffers(ix);
   if (rc) {
     fnv_index_free(ix);
@@ -397,23 +463,20 @@ int fnv_index_view(fnv_index_t src, fnv_index_t* out) {
   v->d_vectors = src->d_vectors;
   v->d_links = src->d_links;
   v->d_labels = src->d_labels;
-  v->visited_factor = src->visited_factor; v->visited_slots = src->visited_slots; v->visited_floor = src->visited_floor;
-  v->occupancy_target = src->occupancy_target; v->occupancy_roomy = src->occupancy_roomy; v->cand_factor = src->cand_factor; v->cand_slots = src->cand_slots;
-  v->spill_entries = src->spill_entries; v->blocks_per_cu = src->blocks_per_cu; v->visited_wide = src->visited_wide;
-  v->entry_kernel = src->entry_kernel; v->output_node_ids = src->output_node_ids; v->visited_tag_bits = src->visited_tag_bits;
-  v->sorted_beam = src->sorted_beam; v->sorted_beam_min = src->sorted_beam_min;
-  v->sorted_cand_lds = src->sorted_cand_lds; v->overflow_list = src->overflow_list;
-  v->sorted_tail_exact_pct = src->sorted_tail_exact_pct;
-  v->beam_registers = src->beam_registers;
-  if (hipSetDevice(v->device) != hipSuccess) {
+  static_cast<IndexOptions&>(*v) = static_cast<const IndexOptions&>(*src);
+  v->parent = src->parent ? src->parent : src;  // a view of a view hangs off the owner
+  DeviceScope scope(v->device);
+  if (scope.err != hipSuccess) {
     delete v;
     return fail(FNV_ERR_NO_DEVICE, "hipSetDevice failed");
   }
   int rc = index_common_init(v);
   if (rc) {
+    v->parent = nullptr;
     fnv_index_free(v);
     return rc;
   }
+  v->parent->n_views.fetch_add(1);
   *out = v;
   return FNV_OK;
 }
@@ -434,7 +497,7 @@ int fnv_index_info(fnv_index_t ix, uint64_t info[8]) {
   info[0] = (uint64_t)ix->dtype;
   info[1] = ix->M;
   info[2] = ix->row_bytes;
-  info[3] = ix->n_nodes;
+  info[3] = ix->parent ? ix->parent->n_nodes : ix->n_nodes;
   info[4] = ix->dim;
   info[5] = (uint64_t)ix->metric;
   info[6] = (uint64_t)ix->device;
@@ -444,8 +507,11 @@ int fnv_index_info(fnv_index_t ix, uint64_t info[8]) {
 
 int fnv_index_free(fnv_index_t ix) {
   if (!ix) return FNV_OK;
-  (void)hipSetDevice(ix->device);
+  if (ix->n_views.load() > 0)
+    return fail(FNV_ERR_INVALID, "fnv_index_free: the index still has live views (fnv_index_view) on its buffers; free them first");
+  DeviceScope scope(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+  if (ix->parent) ix->parent->n_views.fetch_sub(1);
   if (!ix->owns_buffers) ix->d_vectors = nullptr, ix->d_links = nullptr, ix->d_labels = nullptr;
   void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_bitmap, ix->d_ovf, ix->d_nodestage, ix->d_linkstage, ix->d_wirebuf, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase, ix->d_entry};
   for (void* b : bufs)
@@ -487,7 +553,7 @@ int fnv_index_write_links(fnv_index_t ix, const uint32_t* node_ids, const uint32
   if (!ix || ((!node_ids || !link_rows) && count)) return fail(FNV_ERR_INVALID, "null argument");
   if (count == 0) return FNV_OK;
   std::lock_guard<std::mutex> lock(ix->mu);
-  HIP_TRY(hipSetDevice(ix->device));
+  ON_DEVICE(ix->device);
   const size_t need = (size_t)count * (4 + 4ull * ix->M) + sizeof(int);
   if (need > ix->linkstage_bytes) {
     if (ix->d_linkstage) HIP_TRY(hipFree(ix->d_linkstage));
@@ -514,7 +580,7 @@ int fnv_index_write_links(fnv_index_t ix, const uint32_t* node_ids, const uint32
 int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   if (!ix || !name) return fail(FNV_ERR_INVALID, "null argument");
   std::string n(name);
-  if (value < 0 && !(n == "sorted_tail_exact_pct" && value == -1))
+  if (value < 0 && !((n == "sorted_tail_exact_pct" || n == "sorted_variant") && value == -1))
     return fail(FNV_ERR_INVALID, "option values must be non-negative");
   if (n == "visited_factor") ix->visited_factor = std::max<int64_t>(1, value);
   else if (n == "visited_slots") {
@@ -538,6 +604,10 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   else if (n == "sorted_cand_lds") ix->sorted_cand_lds = value;
   else if (n == "sorted_tail_exact_pct") ix->sorted_tail_exact_pct = value;
   else if (n == "beam_registers") ix->beam_registers = value;
+  else if (n == "sorted_variant") {
+    if (value > 4) return fail(FNV_ERR_INVALID, "sorted_variant must be -1 (adaptive) or 0..4");
+    ix->sorted_variant = value;
+  }
   else if (n == "visited_tag_bits") ix->visited_tag_bits = value;
   else return fail(FNV_ERR_INVALID, "unknown option: " + n);
   ix->options_version++;
@@ -648,8 +718,7 @@ static int configure_launch(fnv_index_s* ix, SearchParams& p, kernel_fn kern, in
     }
     size_t pick = sizes.size() - 1;  // roomy
     lds_bytes = lay_out(ix, p, sizes[pick], mode);
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)std::min<uint32_t>(lds_bytes, 160u * 1024u));
+    (void)raise_lds_limit((const void*)kern, ix->device, std::min<uint32_t>(lds_bytes, 160u * 1024u));
     // (a table that holds every id is worth more than the last resident queries: it is kept down to
     // `occupancy_roomy` (9) of them -- measured with the merged-beam kernel at ef 160-200: -4...-18 % time at 9-11 resident
     // queries against a smaller table that overflows at 15; below that the smaller table wins again)
@@ -682,7 +751,7 @@ static int configure_launch(fnv_index_s* ix, SearchParams& p, kernel_fn kern, in
   if (lds_bytes > 160u * 1024u)
     return fail(FNV_ERR_INVALID, "ef_search too large for the on-chip beam state (needs " + std::to_string(lds_bytes) +
                                      " bytes of LDS, 163840 available); lower ef_search or the *_slots options");
-  HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  HIP_TRY(raise_lds_limit((const void*)kern, ix->device, lds_bytes));
   int bpc = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, WAVE, lds_bytes));
   if (bpc < 1) bpc = 1;
@@ -714,7 +783,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   if (!d_queries || !d_out_dist || !d_out_labels) return fail(FNV_ERR_INVALID, "null buffer");
   if (nq > 0x7FFFFFFFull) return fail(FNV_ERR_INVALID, "too many queries in one batch");
   std::lock_guard<std::mutex> lock(ix->mu);
-  HIP_TRY(hipSetDevice(ix->device));
+  ON_DEVICE(ix->device);
   hipStream_t stream = (hipStream_t)hip_stream;
 
   // ---- launch plan: depends on (beam width, K, live geometry, options) only -> cached between calls ------------
@@ -817,7 +886,14 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   const uint64_t round_slots = (uint64_t)plan.sbpc * (uint64_t)ix->num_cus;
   const bool multi_round = sorted && nq > round_slots;
   int64_t tail_pct = ix->sorted_tail_exact_pct < 0 ? 0 : ix->sorted_tail_exact_pct;
-  if (sorted && ix->sorted_beam == 2) {
+  static const int kTailPct[5] = {0, 0, 50, 75, 100};
+  bool exploratory = false;
+  const int pinned = ix->force_variant >= 0 ? ix->force_variant : (int)ix->sorted_variant;  // fnv_tune / "sorted_variant"
+  if (sorted && pinned >= 0) {
+    variant = (pinned >= 2 && !multi_round) ? 1 : pinned;  // an exact tail needs more than one round of queries
+    sorted = variant != 0;
+    if (variant >= 2) tail_pct = kTailPct[variant];
+  } else if (sorted && ix->sorted_beam == 2) {
     if (ix->sample_kernel >= 0 && ix->launched && hipEventQuery(ix->ev1) == hipSuccess) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, ix->ev0, ix->ev1) == hipSuccess && ms > 0.f) {
@@ -832,11 +908,12 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
       fnv_index_s::Tuner& t = ix->tuner[2 * B + (multi_round ? 1 : 0)];
       const bool try_tail = multi_round && ix->sorted_tail_exact_pct < 0;
       // three samples each (the first launch of a kernel is a cold one; the best of the rest decides), then the fastest
-      static const int kTailPct[5] = {0, 0, 50, 75, 100};
+      // (fnv_tune takes all the samples in one call, so that no caller's launch is an exploratory one)
       const int nvar = try_tail ? 5 : 2;
       variant = -1;
       for (int v : {1, 0, 4, 3, 2})
         if (v < nvar && variant < 0 && t.samples[v] < 3) variant = v;
+      exploratory = variant >= 0;
       if (variant < 0) {
         variant = 0;
         for (int v = 1; v < nvar; v++)
@@ -866,13 +943,14 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   p.out_count = d_out_count;
   p.out_ndist = d_out_ndist;
   p.out_nhops = d_out_nhops;
-  p.n_nodes = ix->n_nodes;
+  const uint64_t live = ix->parent ? ix->parent->n_nodes : ix->n_nodes;  // a view follows its source's growth
+  p.n_nodes = live;
   p.nq = (uint32_t)nq;
   // Index.h:851-861: step = max(1, N / n_init); nodes 0, step, 2*step, ... < N
-  uint64_t step = ix->n_nodes / (uint64_t)num_initializations;
+  uint64_t step = live / (uint64_t)num_initializations;
   if (step == 0) step = 1;
   p.scan_step = (uint32_t)step;
-  p.n_scan = (uint32_t)((ix->n_nodes + step - 1) / step);
+  p.n_scan = (uint32_t)((live + step - 1) / step);
   p.ovf_bitmap = ix->d_bitmap;
   p.ovf_glist = ix->d_ovf;
   p.cand_spill = ix->d_spill;
@@ -895,20 +973,22 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     p.scan_tile_rows = std::max<uint32_t>(1, std::min<uint32_t>(p.n_scan, (64u * 1024u) / p.scan_tile_stride));
     const uint32_t scan_lds = fixed + p.scan_tile_rows * p.scan_tile_stride;
     kernel_fn scan = pick_scan_kernel(ix->dtype, ix->metric, plan.cfg, plan.full);
-    HIP_TRY(hipFuncSetAttribute((const void*)scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
+    HIP_TRY(raise_lds_limit((const void*)scan, ix->device, scan_lds));
     hipLaunchKernelGGL(scan, dim3((unsigned)((nq + SCAN_QPB - 1) / SCAN_QPB)), dim3(SCAN_WAVES * WAVE), scan_lds, stream, p);
     HIP_TRY(hipGetLastError());
     p.entry_node = p.entry_node_out;
     p.entry_dist = p.entry_dist_out;
   }
   kernel_fn kern = sorted ? plan.skern : plan.kern;
-  HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  HIP_TRY(raise_lds_limit((const void*)kern, ix->device, lds_bytes));
   hipLaunchKernelGGL(kern, dim3(nslots), dim3(WAVE), lds_bytes, stream, p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ix->ev1, stream));
   ix->sample_kernel = sample ? variant : -1;
   ix->sample_B = 2 * B + (multi_round ? 1 : 0);
   ix->sample_nq = nq;
+  ix->last_variant = sorted ? std::max(variant, 1) : 0;
+  ix->last_exploratory = exploratory;
   ix->last_stream = stream;
   ix->launched = true;
   ix->geom[0] = nslots;
@@ -925,7 +1005,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
 int fnv_search_status(fnv_index_t ix) {
   if (!ix) return fail(FNV_ERR_INVALID, "index is null");
   if (!ix->launched) return FNV_OK;
-  HIP_TRY(hipSetDevice(ix->device));
+  ON_DEVICE(ix->device);
   HIP_TRY(hipStreamSynchronize(ix->last_stream));
   int32_t st = 0;
   HIP_TRY(hipMemcpy(&st, ix->d_dispenser + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -934,13 +1014,17 @@ int fnv_search_status(fnv_index_t ix) {
   return FNV_OK;
 }
 
+static uint64_t now_ns() {
+  return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 // Host-buffer search in two halves, so that several devices can be kept busy by one caller: enqueue (H2D of the
 // queries, the search launch, D2H of the results -- all asynchronous on the index's own stream; the caller holds
 // ix->host_mu) and finish (wait, report a capacity error).
 static int search_host_enqueue(fnv_index_t ix, const void* queries, uint64_t nq, int K, int ef_search,
                                int num_initializations, float* out_dist, int32_t* out_labels, int32_t* out_count,
                                uint64_t* out_ndist, uint64_t* out_nhops) {
-  HIP_TRY(hipSetDevice(ix->device));
+  ON_DEVICE(ix->device);
   const size_t qbytes = (size_t)nq * ix->dim * dtype_size(ix->dtype);
   // one output slab: dist | labels | count | ndist | nhops
   const size_t o_dist = 0;
@@ -974,6 +1058,7 @@ static int search_host_enqueue(fnv_index_t ix, const void* queries, uint64_t nq,
                                    (int32_t*)(o + o_lab), (int32_t*)(o + o_cnt), (uint64_t*)(o + o_nd),
                                    (uint64_t*)(o + o_nh), ix->stream);
   if (rc) return rc;
+  ix->t_enqueue_ns = now_ns();
   if (pinned) {
     uint8_t* h = (uint8_t*)ix->h_pin;
     HIP_TRY(hipMemcpyAsync(h + ooff, o, obytes, hipMemcpyDeviceToHost, ix->stream));
@@ -997,8 +1082,9 @@ static int search_host_enqueue(fnv_index_t ix, const void* queries, uint64_t nq,
 }
 
 static int search_host_finish(fnv_index_t ix) {
-  HIP_TRY(hipSetDevice(ix->device));
+  ON_DEVICE(ix->device);
   HIP_TRY(hipStreamSynchronize(ix->stream));
+  ix->t_complete_ns = now_ns();
   PinnedCall& c = ix->pin;
   if (!c.active) return fnv_search_status(ix);
   c.active = false;
@@ -1058,7 +1144,7 @@ int fnv_replicate(fnv_index_t src, int n_devices, const int* devices, fnv_index_
       return rc;
     }
   }
-  int rc = fnv_replica_refresh(src, n_devices, out);
+  int rc = fnv_replica_refresh(src, n_devices, out);  // also hands the source's options to every replica
   if (rc) undo();
   return rc;
 }
@@ -1066,6 +1152,12 @@ int fnv_replicate(fnv_index_t src, int n_devices, const int* devices, fnv_index_
 int fnv_replica_refresh(fnv_index_t src, int n_replicas, fnv_index_t* replicas) {
   if (!src || (!replicas && n_replicas)) return fail(FNV_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lock(src->mu);
+  int caller_device = -1;
+  (void)hipGetDevice(&caller_device);
+  struct Restore {
+    int dev;
+    ~Restore() { if (dev >= 0) (void)hipSetDevice(dev); }
+  } restore{caller_device};
   const uint64_t live = src->n_nodes;
   const size_t bytes[3] = {(size_t)live * src->row_bytes, (size_t)live * src->M * 4, (size_t)live * 4};
   for (int i = 0; i < n_replicas; i++) {
@@ -1073,6 +1165,16 @@ int fnv_replica_refresh(fnv_index_t src, int n_replicas, fnv_index_t* replicas) 
     if (!r || r->capacity < live || r->row_bytes != src->row_bytes || r->M != src->M || r->dtype != src->dtype ||
         r->metric != src->metric)
       return fail(FNV_ERR_INVALID, "fnv_replica_refresh: replica geometry does not match the source index");
+  }
+  // A replica answers its shard of a batch exactly as the source would: same options (kernel choice, node ids vs
+  // labels, table sizes ...), whatever they were when the replica was made.
+  for (int i = 0; i < n_replicas; i++) {
+    fnv_index_t r = replicas[i];
+    std::lock_guard<std::mutex> rl(r->mu);
+    static_cast<IndexOptions&>(*r) = static_cast<const IndexOptions&>(*src);
+    r->options_version++;
+    r->tuner.clear();
+    r->sample_kernel = -1;
   }
   // Doubling tree of peer copies over xGMI: in every round each index that already holds the data feeds one that
   // does not (1 -> 2 -> 4 -> 8 holders: three rounds for eight GPUs, every link busy once per round).  The copies
@@ -1110,7 +1212,6 @@ int fnv_replica_refresh(fnv_index_t src, int n_replicas, fnv_index_t* replicas) 
       have.push_back(to);
     }
   }
-  HIP_TRY(hipSetDevice(src->device));
   return FNV_OK;
 }
 
@@ -1123,36 +1224,145 @@ int fnv_search_batch_multi(fnv_index_t* indexes, int n_indexes, const void* quer
   for (int g = 1; g < n_indexes; g++)
     if (!indexes[g] || indexes[g]->dim != indexes[0]->dim || indexes[g]->dtype != indexes[0]->dtype)
       return fail(FNV_ERR_INVALID, "fnv_search_batch_multi: indexes differ in geometry");
-  // rows [g * ceil(Q/G), ...) go to index g; every device gets its H2D copy, launch and D2H copies
-  // enqueued on its own stream before the first one is waited for
+  for (int g = 1; g < n_indexes; g++)
+    if (indexes[g]->output_node_ids != indexes[0]->output_node_ids)
+      return fail(FNV_ERR_INVALID, "fnv_search_batch_multi: indexes differ in the output_node_ids option (labels and node ids would mix)");
+  // Rows [g * ceil(Q/G), ...) go to index g.  Every shard is driven by its own host thread (shard 0 by
+  // the caller's): a shard of the bench shape is 5 MB of pageable queries, and a pageable hipMemcpyAsync blocks its
+  // host thread until the copy has been staged -- issued from ONE thread, GPU g+1 would not be launched before GPU g's
+  // copy (and, on one stream per device, its kernel) had been waited for.  With a thread per device the staging copies,
+  // launches and waits of all devices overlap, and hipSetDevice (per-thread state) never touches the caller's device.
   const uint64_t per = (nq + (uint64_t)n_indexes - 1) / (uint64_t)n_indexes;
   const size_t qrow = (size_t)indexes[0]->dim * dtype_size(indexes[0]->dtype);
-  std::vector<std::unique_lock<std::mutex>> locks;
-  int first_error = FNV_OK;
-  std::string first_msg;
-  int enqueued = 0;
-  for (int g = 0; g < n_indexes; g++) {
+  int shards = 0;
+  for (int g = 0; g < n_indexes; g++)
+    if (std::min<uint64_t>(nq, (uint64_t)g * per) < nq) shards = g + 1;
+  std::vector<int> rcs((size_t)shards, FNV_OK);
+  std::vector<std::string> msgs((size_t)shards);
+  auto run_shard = [&](int g) {
     const uint64_t lo = std::min<uint64_t>(nq, (uint64_t)g * per), hi = std::min<uint64_t>(nq, lo + per);
-    if (hi == lo) break;
-    locks.emplace_back(indexes[g]->host_mu);
-    rc = search_host_enqueue(indexes[g], (const uint8_t*)queries + lo * qrow, hi - lo, K, ef_search, num_initializations,
-                             out_dist + lo * K, out_labels + lo * K, out_count ? out_count + lo : nullptr,
-                             out_ndist ? out_ndist + lo : nullptr, out_nhops ? out_nhops + lo : nullptr);
-    enqueued = g + 1;
-    if (rc) {
-      first_error = rc;
-      first_msg = g_err;
-      break;
-    }
+    rcs[g] = fnv_search_batch(indexes[g], (const uint8_t*)queries + lo * qrow, hi - lo, K, ef_search, num_initializations,
+                              out_dist + lo * K, out_labels + lo * K, out_count ? out_count + lo : nullptr,
+                              out_ndist ? out_ndist + lo : nullptr, out_nhops ? out_nhops + lo : nullptr);
+    if (rcs[g]) msgs[g] = g_err;  // thread-local: carried back by hand
+  };
+  std::vector<std::thread> workers;
+  for (int g = 1; g < shards; g++) workers.emplace_back(run_shard, g);
+  run_shard(0);
+  for (std::thread& w : workers) w.join();
+  for (int g = 0; g < shards; g++)
+    if (rcs[g]) return fail(rcs[g], msgs[g]);
+  return FNV_OK;
+}
+
+// ---- the adaptive kernel choice, taken in one go --------------------------------------------------------------------
+// Runs every variant the adaptive choice ("sorted_beam" = 2) would try for this (beam width, batch size class) on the
+// caller's queries -- a cold launch plus three timed ones each -- and settles the choice, so that the caller's own
+// launches never are exploratory ones.  Results are discarded (scratch buffers of the index).
+int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_device, int K, int ef_search,
+             int num_initializations) {
+  if (!ix) return fail(FNV_ERR_INVALID, "index is null");
+  if (num_initializations <= 0) return fail(FNV_ERR_INVALID, "num_initializations must be greater than 0.");
+  if (K <= 0 || ef_search <= 0) return fail(FNV_ERR_INVALID, "K and ef_search must be positive");
+  if (!queries || nq == 0) return fail(FNV_ERR_INVALID, "fnv_tune needs a batch of queries");
+  std::lock_guard<std::mutex> host_lock(ix->host_mu);
+  ON_DEVICE(ix->device);
+  const size_t qbytes = (size_t)nq * ix->dim * dtype_size(ix->dtype);
+  const size_t o_lab = (size_t)nq * K * 4, obytes = 2 * o_lab;
+  {
+    std::lock_guard<std::mutex> lock(ix->mu);
+    int rc = queries_on_device ? FNV_OK : grow(&ix->d_q, &ix->d_q_bytes, qbytes);
+    if (!rc) rc = grow(&ix->d_out, &ix->d_out_bytes, obytes);
+    if (rc) return rc;
   }
-  for (int g = 0; g < enqueued; g++) {
-    rc = search_host_finish(indexes[g]);
-    if (rc && !first_error) {
-      first_error = rc;
-      first_msg = g_err;
-    }
+  const void* dq = queries;
+  if (!queries_on_device) {
+    HIP_TRY(hipMemcpy(ix->d_q, queries, qbytes, hipMemcpyHostToDevice));
+    dq = ix->d_q;
   }
-  if (first_error) return fail(first_error, first_msg);
+  uint8_t* o = (uint8_t*)ix->d_out;
+  auto launch = [&](int variant) -> int {
+    ix->force_variant = variant;
+    const int rc = search_device_impl(ix, dq, nq, K, ef_search, num_initializations, (float*)o, (int32_t*)(o + o_lab), nullptr,
+                                      nullptr, nullptr, ix->stream, ix->output_node_ids != 0);
+    ix->force_variant = -1;
+    return rc;
+  };
+  // what kind of launch is this?  (one probing launch of the merged-beam kernel tells: plan, round size)
+  int rc = launch(1);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  if (ix->geom[6] == MODE_HEAPS || ix->sorted_beam != 2 || ix->sorted_variant >= 0 || nq < 2048) return FNV_OK;  // nothing to choose
+  const int B = std::max(ef_search, K);
+  const bool multi_round = nq > (uint64_t)ix->plan.sbpc * (uint64_t)ix->num_cus;
+  const int nvar = (multi_round && ix->sorted_tail_exact_pct < 0) ? 5 : 2;
+  fnv_index_s::Tuner t;
+  for (int v = 0; v < nvar; v++) {
+    for (int rep = 0; rep < 4; rep++) {
+      rc = launch(v);
+      if (rc) return rc;
+      HIP_TRY(hipStreamSynchronize(ix->stream));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
+      const float per_q = ms / (float)nq;
+      if (rep > 0 && (t.samples[v] == 0 || per_q < t.best[v])) t.best[v] = per_q;  // the first launch of a kernel is a cold one
+      if (rep > 0) t.samples[v]++;
+    }
+    t.samples[v] = 4;  // settled: later launches neither explore nor sample
+  }
+  {
+    std::lock_guard<std::mutex> lock(ix->mu);
+    ix->tuner[2 * B + (multi_round ? 1 : 0)] = t;
+    ix->sample_kernel = -1;
+  }
+  int32_t st = 0;
+  HIP_TRY(hipMemcpy(&st, ix->d_dispenser + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (st == ST_CAND_OVERFLOW)
+    return fail(FNV_ERR_CAPACITY, "candidate heap overflowed its HBM spill area; raise the spill_entries option");
+  return FNV_OK;
+}
+
+// Measurement aid: the rate (GB/s of row bytes) a pure gather of random rows of this index's vector table reaches with
+// the search kernel's own load pattern for this row width (relayout.hpp: gather_ceiling_kernel) at `waves_per_cu`
+// resident waves (0: 16).  ~20-40 ms of GPU time.
+int fnv_gather_ceiling(fnv_index_t ix, int waves_per_cu, double* gbps_out) {
+  if (!ix || !gbps_out) return fail(FNV_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lock(ix->mu);
+  ON_DEVICE(ix->device);
+  const uint64_t n_rows = ix->parent ? ix->parent->n_nodes : ix->n_nodes;
+  const uint32_t nchunks = ix->row_bytes / 16;
+  const int cfg = pick_row_cfg(nchunks);
+  typedef void (*gather_fn)(const uint8_t*, uint64_t, uint32_t, int, uint32_t*);
+  static const gather_fn kGather[kNumCfgs] = {gather_ceiling_kernel<8, 1>,  gather_ceiling_kernel<8, 2>,  gather_ceiling_kernel<8, 4>,
+                                              gather_ceiling_kernel<16, 4>, gather_ceiling_kernel<32, 4>, gather_ceiling_kernel<64, 4>,
+                                              gather_ceiling_kernel<64, 3>};
+  const int G = kCfgs[cfg].G, CU = kCfgs[cfg].CU;
+  const int PU = (G == 64 && CU == 3) ? 4 : PU_DEFAULT;
+  const int wpc = waves_per_cu > 0 ? std::min(waves_per_cu, 32) : 16;
+  const uint32_t blocks = (uint32_t)(ix->num_cus * wpc);
+  const double rows_per_iter = (double)blocks * (WAVE / G) * PU;  // rows one iteration of the whole grid reads
+  const int iters = (int)std::max<double>(8.0, 120e9 / (rows_per_iter * (double)ix->row_bytes));  // ~120 GB ~ 20 ms
+  uint32_t* d_sink = ix->d_dispenser + 2;  // an unused word of the workspace
+  hipLaunchKernelGGL(kGather[cfg], dim3(blocks), dim3(WAVE), 0, ix->stream, ix->d_vectors, n_rows, ix->row_bytes, iters / 8 + 1, d_sink);  // warm
+  HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
+  hipLaunchKernelGGL(kGather[cfg], dim3(blocks), dim3(WAVE), 0, ix->stream, ix->d_vectors, n_rows, ix->row_bytes, iters, d_sink);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
+  HIP_TRY(hipEventSynchronize(ix->ev1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
+  ix->sample_kernel = -1;  // ev0 / ev1 no longer bracket a search launch
+  *gbps_out = rows_per_iter * (double)iters * (double)ix->row_bytes / 1e9 / ((double)ms / 1e3);
+  return FNV_OK;
+}
+
+int fnv_last_launch_info(fnv_index_t ix, uint64_t info[4]) {
+  if (!ix || !info) return fail(FNV_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lock(ix->mu);
+  info[0] = (uint64_t)ix->last_variant;
+  info[1] = ix->last_exploratory ? 1u : 0u;
+  info[2] = ix->t_enqueue_ns;
+  info[3] = ix->t_complete_ns;
   return FNV_OK;
 }
 
@@ -1169,7 +1379,7 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
   if (evals_out) *evals_out = 0;
   if (count == 0) return FNV_OK;
   std::lock_guard<std::mutex> host_lock(ix->host_mu);
-  HIP_TRY(hipSetDevice(ix->device));
+  ON_DEVICE(ix->device);
   const int W = ef_construction;
   const uint32_t keep = std::max<uint32_t>(ix->M / 2, 1);  // Index.h:373
   const size_t esize = dtype_size(ix->dtype);
@@ -1253,7 +1463,7 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
                         pick_connect_kernel(ix->dtype, ix->metric, cfg, full)};
   for (int phase = 0; phase < 2; phase++) {
     wire_fn kern = kernels[phase];
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HIP_TRY(raise_lds_limit((const void*)kern, ix->device, lds_bytes));
     int bpc = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, WAVE, lds_bytes));
     if (bpc < 1) bpc = 1;
@@ -1296,7 +1506,7 @@ int fnv_index_read_links(fnv_index_t ix, uint64_t first_node, uint64_t count, ui
     return fail(FNV_ERR_INVALID, "node range outside the device index");
   if (count == 0) return FNV_OK;
   std::lock_guard<std::mutex> lock(ix->mu);
-  HIP_TRY(hipSetDevice(ix->device));
+  ON_DEVICE(ix->device);
   HIP_TRY(hipMemcpy(out_rows, ix->d_links + first_node * (uint64_t)ix->M, count * 4ull * ix->M, hipMemcpyDeviceToHost));
   return FNV_OK;
 }
@@ -1304,7 +1514,7 @@ int fnv_index_read_links(fnv_index_t ix, uint64_t first_node, uint64_t count, ui
 int fnv_last_kernel_ms(fnv_index_t ix, float* ms) {
   if (!ix || !ms) return fail(FNV_ERR_INVALID, "null argument");
   if (!ix->launched) return fail(FNV_ERR_RUNTIME, "no search has been launched on this index");
-  HIP_TRY(hipSetDevice(ix->device));
+  ON_DEVICE(ix->device);
   HIP_TRY(hipEventSynchronize(ix->ev1));
   HIP_TRY(hipEventElapsedTime(ms, ix->ev0, ix->ev1));
   return FNV_OK;
@@ -1323,7 +1533,7 @@ int fnv_debug_heap_microbench(int size, int iters, int blocks, uint64_t out[4]) 
 // Profiling builds only: cumulative shader cycles per kernel phase (and reset).
 int fnv_debug_phase_cycles(fnv_index_t ix, uint64_t out[16]) {
   if (!ix || !out) return fail(FNV_ERR_INVALID, "null argument");
-  HIP_TRY(hipSetDevice(ix->device));
+  ON_DEVICE(ix->device);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out, ix->d_phase, NPHASE * sizeof(uint64_t), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemset(ix->d_phase, 0, NPHASE * sizeof(uint64_t)));
@@ -1335,7 +1545,7 @@ int fnv_last_replayed_queries(fnv_index_t ix, uint64_t out[5]) {
   if (!ix || !out) return fail(FNV_ERR_INVALID, "null argument");
   for (int i = 0; i < 5; i++) out[i] = 0;
   if (!ix->launched) return FNV_OK;
-  HIP_TRY(hipSetDevice(ix->device));
+  ON_DEVICE(ix->device);
   HIP_TRY(hipStreamSynchronize(ix->last_stream));
   uint32_t w[5];
   HIP_TRY(hipMemcpy(w, ix->d_dispenser + 3, sizeof(w), hipMemcpyDeviceToHost));

@@ -218,7 +218,7 @@ void bindIndex(py::module_& m, const char* name) {
       .def("set_device", &T::setDevice, py::arg("ordinal"), "Use this one GPU.")
       .def("set_devices", &T::setDevices, py::arg("ordinals"),
            "GPUs that each hold a replica of the index; batched searches are sharded over them (default: the "
-           "FLATNAV_DEVICES environment variable, else every visible GPU).")
+           "FLATNAV_DEVICES environment variable -- 'all' = every visible GPU --, else the primary GPU only).")
       .def_property_readonly("devices", &T::devices)
       .def("sync_device", &T::syncDevice, "Upload pending changes to HBM now instead of at the next search.")
       .def("device_handle", &T::deviceHandle, "fnv_index_t of the device mirror as an integer.")

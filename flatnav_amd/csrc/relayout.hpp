@@ -103,6 +103,47 @@ __global__ void relayout_links_kernel(const uint8_t* __restrict__ aos, uint64_t 
   labels[first_node + node] = lab;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Gather ceiling (measurement aid, fnv_gather_ceiling): what the search kernel's access pattern reaches on THIS index's
+// vector table with no other work -- random rows, read as 16-byte chunks by G-lane groups (whole 128-byte lines),
+// PU x CU loads in flight per lane, exactly the (G, CU, passes) the search kernel uses for this row width.  The rate
+// it reaches is the practical bound of roofline.achieved for this (row bytes, table size): part of a small table is
+// served by the 256 MiB Infinity Cache, rows that are not whole lines pay for the lines they straddle.
+// ---------------------------------------------------------------------------------------------
+template <int G, int CU>
+__global__ __launch_bounds__(WAVE) void gather_ceiling_kernel(const uint8_t* __restrict__ base, uint64_t n_rows,
+                                                              uint32_t row_bytes, int iters, uint32_t* out) {
+  constexpr int PU = passes<G, CU>();
+  const int lane = threadIdx.x, g = lane % G;
+  uint32_t rng = (blockIdx.x * WAVE + lane / G * G) * 2654435761u + 12345u;  // same within a G-lane group
+  uint32_t acc = 0;
+  const int nchunks = (int)(row_bytes / 16);
+  for (int it = 0; it < iters; it++) {
+    const uint8_t* rowp[PU];
+#pragma unroll
+    for (int pu = 0; pu < PU; pu++) {
+      rng = rng * 1664525u + 1013904223u;
+      const uint64_t row = ((uint64_t)(rng >> 4) * n_rows) >> 28;
+      rowp[pu] = base + row * row_bytes;
+    }
+    for (int c0 = 0; c0 < nchunks; c0 += G * CU) {
+      uint4 y[PU][CU];
+#pragma unroll
+      for (int pu = 0; pu < PU; pu++)
+#pragma unroll
+        for (int cu = 0; cu < CU; cu++) {
+          const int c = c0 + cu * G + g;
+          y[pu][cu] = *reinterpret_cast<const uint4*>(rowp[pu] + (uint32_t)(c < nchunks ? c : nchunks - 1) * 16u);
+        }
+#pragma unroll
+      for (int pu = 0; pu < PU; pu++)
+#pragma unroll
+        for (int cu = 0; cu < CU; cu++) acc ^= y[pu][cu].x ^ y[pu][cu].y ^ y[pu][cu].z ^ y[pu][cu].w;
+    }
+  }
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
 __global__ void iota_kernel(uint32_t* out, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = i;

@@ -25,7 +25,7 @@ C_ABI_SYMBOLS = [
     "fnv_search_batch_device", "fnv_search_status", "fnv_last_kernel_ms", "fnv_last_launch_geometry",
     "fnv_index_set_live_nodes", "fnv_index_write_nodes", "fnv_index_write_links", "fnv_index_insert_batch",
     "fnv_index_read_links", "fnv_last_replayed_queries", "fnv_replicate", "fnv_replica_refresh",
-    "fnv_search_batch_multi", "fnv_index_view",
+    "fnv_search_batch_multi", "fnv_index_view", "fnv_tune", "fnv_last_launch_info", "fnv_gather_ceiling",
 ]
 
 _lib = None
@@ -76,6 +76,9 @@ def lib() -> C.CDLL:
     L.fnv_replica_refresh.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     L.fnv_search_batch_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_int,
                                          C.c_int] + [C.c_void_p] * 5
+    L.fnv_tune.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.fnv_last_launch_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.fnv_gather_ceiling.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -161,8 +164,9 @@ class DeviceIndex:
     def close(self) -> None:
         if getattr(self, "_h", None):
             if getattr(self, "_owned", True):
-                lib().fnv_index_free(self._h)
+                check(lib().fnv_index_free(self._h))  # fails (ValueError) while views of this handle are alive
             self._h = None
+            self._parent = None
 
     def __del__(self):
         try:
@@ -212,7 +216,9 @@ class DeviceIndex:
         """A second handle on the same device buffers with its own workspace: two searches in flight on one index."""
         h = C.c_void_p()
         check(lib().fnv_index_view(self._h, C.byref(h)))
-        return DeviceIndex(h)
+        v = DeviceIndex(h)
+        v._parent = self  # the view aliases this handle's buffers: keep it alive (the library refuses to free it first)
+        return v
 
     def replicate(self, devices) -> list:
         """Replicas of this index on the given device ordinals (peer copies over xGMI); each is an independent handle."""
@@ -256,6 +262,32 @@ class DeviceIndex:
         check(lib().fnv_search_batch_device(self._h, q_ptr, nq, K, ef_search, num_initializations, dist_ptr,
                                             label_ptr, count_ptr or None, ndist_ptr or None, nhops_ptr or None,
                                             stream or None))
+
+    def tune(self, queries, K: int, ef_search: int, num_initializations: int = 100, nq: int = 0) -> None:
+        """Settle the adaptive kernel choice for (K, ef_search, this batch size) in one call (fnv_tune): afterwards no
+        launch of that shape is an exploratory one.  `queries`: host array [Q, dim], or a device pointer (int) + nq."""
+        if isinstance(queries, int):
+            check(lib().fnv_tune(self._h, queries, int(nq), 1, K, ef_search, num_initializations))
+            return
+        q = np.ascontiguousarray(queries, dtype=_np_dtype(self.dtype))
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError("Queries have incorrect dimensions.")
+        check(lib().fnv_tune(self._h, q.ctypes.data, q.shape[0], 0, K, ef_search, num_initializations))
+
+    def launch_info(self) -> dict:
+        """Variant of the most recent launch, whether it was an exploratory sample of the adaptive choice, and the host
+        timestamps (ns, steady clock) of the most recent host-buffer search."""
+        r = (C.c_uint64 * 4)()
+        check(lib().fnv_last_launch_info(self._h, r))
+        names = ["two_heaps", "merged_beam", "merged_beam_tail50", "merged_beam_tail75", "merged_beam_tail100"]
+        return {"variant": names[int(r[0])], "variant_id": int(r[0]), "exploratory": bool(r[1]),
+                "enqueued_ns": int(r[2]), "completed_ns": int(r[3])}
+
+    def gather_ceiling(self, waves_per_cu: int = 0) -> float:
+        """GB/s of row bytes a pure random-row gather of this index's vector table reaches (fnv_gather_ceiling)."""
+        v = C.c_double(0)
+        check(lib().fnv_gather_ceiling(self._h, int(waves_per_cu), C.byref(v)))
+        return float(v.value)
 
     def status(self) -> None:
         check(lib().fnv_search_status(self._h))

@@ -203,8 +203,8 @@ class Index {
   int _device_ordinal = 0;
   // several GPUs: the mirror on _device_ordinal is the primary; replicas of it live on the other devices of
   // _device_list (filled by peer copies, refreshed whenever the primary changes); batches are sharded over all of them
-  mutable std::vector<int> _device_list;   // empty: not decided yet (FLATNAV_DEVICES, else every visible GPU)
-  mutable bool _device_list_defaulted = false;  // "every visible GPU" was assumed, not asked for
+  mutable std::vector<int> _device_list;   // empty: not decided yet (FLATNAV_DEVICES, else the primary GPU alone)
+  mutable bool _device_list_defaulted = false;  // FLATNAV_DEVICES=all: "every visible GPU", whatever that turns out to be
   mutable std::vector<fnv_index_t> _replicas;
   mutable bool _replicas_stale = true;
 
@@ -392,18 +392,25 @@ class Index {
                              _device_synced_nodes > 0 && _device_synced_nodes <= _cur_num_nodes &&
                              _dirty_rows.count() <= _cur_num_nodes / 4;
     if (incremental) {
+      // The marks are drained before the writes: if a write fails they are gone, so the mirror is declared untracked
+      // (next call ships the whole store) before the error goes up -- never a silently diverged device graph.
       std::vector<node_id_t> ids = _dirty_rows.drain(_device_synced_nodes);
-      if (_cur_num_nodes > _device_synced_nodes)
-        detail::throwOnDeviceError(fnv_index_write_nodes(_device_index, _device_synced_nodes,
-                                                         _cur_num_nodes - _device_synced_nodes,
-                                                         nodeData(static_cast<node_id_t>(_device_synced_nodes)),
-                                                         _node_size_bytes, _data_size_bytes));
-      if (!ids.empty()) {
-        std::vector<node_id_t> rows(ids.size() * _M);
-        for (size_t t = 0; t < ids.size(); ++t) std::memcpy(rows.data() + t * _M, nodeLinks(ids[t]), _M * sizeof(node_id_t));
-        detail::throwOnDeviceError(fnv_index_write_links(_device_index, ids.data(), rows.data(), ids.size()));
+      try {
+        if (_cur_num_nodes > _device_synced_nodes)
+          detail::throwOnDeviceError(fnv_index_write_nodes(_device_index, _device_synced_nodes,
+                                                           _cur_num_nodes - _device_synced_nodes,
+                                                           nodeData(static_cast<node_id_t>(_device_synced_nodes)),
+                                                           _node_size_bytes, _data_size_bytes));
+        if (!ids.empty()) {
+          std::vector<node_id_t> rows(ids.size() * _M);
+          for (size_t t = 0; t < ids.size(); ++t) std::memcpy(rows.data() + t * _M, nodeLinks(ids[t]), _M * sizeof(node_id_t));
+          detail::throwOnDeviceError(fnv_index_write_links(_device_index, ids.data(), rows.data(), ids.size()));
+        }
+        detail::throwOnDeviceError(fnv_index_set_live_nodes(_device_index, _cur_num_nodes));
+      } catch (...) {
+        const_cast<Index*>(this)->markDeviceRebuild();
+        throw;
       }
-      detail::throwOnDeviceError(fnv_index_set_live_nodes(_device_index, _cur_num_nodes));
     } else {
       if (_device_index) {
         fnv_index_free(_device_index);
@@ -439,22 +446,26 @@ class Index {
   }
 
   // The GPUs this index spreads its batches over: setDevices(), else the FLATNAV_DEVICES environment variable
-  // ("0,1,2,3"; an ordinal may repeat -- tests put two replicas on one GPU), else every visible device.
+  // ("0,1,2,3" -- an ordinal may repeat: tests put two replicas on one GPU -- or "all" = every visible device), else
+  // the primary GPU alone: a library must not allocate a full index copy on every GPU of the node, nor move work to
+  // devices the caller did not name, unasked.
   void resolveDeviceList() const {
     if (!_device_list.empty()) return;
     if (const char* env = std::getenv("FLATNAV_DEVICES")) {
-      std::stringstream ss(env);
-      for (std::string tok; std::getline(ss, tok, ',');)
-        if (!tok.empty()) _device_list.push_back(std::stoi(tok));
+      if (std::string(env) == "all") {  // the primary first, then every other visible GPU
+        int count = 1;
+        if (fnv_device_count(&count) != FNV_OK || count < 1) count = 1;
+        _device_list.push_back(_device_ordinal);
+        for (int d = 0; d < count; ++d)
+          if (d != _device_ordinal) _device_list.push_back(d);
+        _device_list_defaulted = true;  // a replication failure falls back to the primary with a warning
+      } else {
+        std::stringstream ss(env);
+        for (std::string tok; std::getline(ss, tok, ',');)
+          if (!tok.empty()) _device_list.push_back(std::stoi(tok));
+      }
     }
-    if (_device_list.empty()) {
-      int count = 1;
-      if (fnv_device_count(&count) != FNV_OK || count < 1) count = 1;
-      _device_list.push_back(_device_ordinal);
-      for (int d = 0; d < count; ++d)
-        if (d != _device_ordinal) _device_list.push_back(d);
-      _device_list_defaulted = true;
-    }
+    if (_device_list.empty()) _device_list.push_back(_device_ordinal);  // nobody asked for more: the primary GPU only
     const_cast<Index*>(this)->_device_ordinal = _device_list[0];
   }
 
@@ -521,7 +532,7 @@ class Index {
   void setDevice(int ordinal) { setDevices(std::vector<int>{ordinal}); }
   // The GPUs that hold a copy of the index; batched searches are sharded over all of them (rows
   // [g * ceil(Q/G), ...) to the g-th), like the reference shards a batch over host threads
-  // (bindings.cpp:198-211).  Default: FLATNAV_DEVICES, else every visible GPU.
+  // (bindings.cpp:198-211).  Default: FLATNAV_DEVICES ("all" = every visible GPU), else the primary GPU only.
   void setDevices(const std::vector<int>& ordinals) {
     if (ordinals.empty()) throw std::invalid_argument("setDevices: at least one device ordinal is required");
     std::lock_guard<std::mutex> g(_device_guard);
@@ -666,6 +677,14 @@ class Index {
       ~RestoreLabels() { fnv_set_option(ix, "output_node_ids", 0); }
     } restore{_device_index};
 
+    // A device call that throws mid-batch leaves host store and mirror out of step in ways nothing tracks: the mirror
+    // is rebuilt from the host store by the next ensureDevice().
+    struct RebuildOnError {
+      Index* self;
+      bool armed = true;
+      ~RebuildOnError() { if (armed) self->markDeviceRebuild(); }
+    } rebuild_guard{this};
+
     const bool device_wiring = opt.wire_on_device && _M <= 64;
     const uint64_t first_device_node = _cur_num_nodes;
     const int width = ef_construction;
@@ -764,6 +783,7 @@ class Index {
     _device_synced_nodes = _cur_num_nodes;
     _device_stale = _device_rebuild = false;
     _replicas_stale = true;
+    rebuild_guard.armed = false;
   }
 
   void add(void* data, label_t& label, int ef_construction, int num_initializations) {

@@ -65,7 +65,7 @@ enum { FNV_METRIC_L2 = 0, FNV_METRIC_IP = 1 };
 /* Message of the last failing call on this thread (never NULL). */
 const char* fnv_last_error(void);
 
-/* Library / build identification, e.g. "flatnav_hip gfx950 r2". */
+/* Library / build identification, e.g. "flatnav_hip gfx950 r3". */
 const char* fnv_version(void);
 
 /* Number of visible HIP devices. */
@@ -73,7 +73,10 @@ int fnv_device_count(int* count);
 
 /* Upload a host AoS index blob (exactly the bytes flatnav keeps in _index_memory / writes to its
  * .bin file after the 60-byte header) to `device` and re-lay it out for the GPU:
- *   vectors [n_nodes][row_bytes]  (row_bytes = data_size rounded up to 16, zero padded)
+ *   vectors [n_nodes][row_bytes]  (row_bytes = data_size rounded up to 16 bytes, and on to whole 128-byte lines
+ *                                  when that pads by at most FLATNAV_ROW_PAD_PCT per cent -- environment variable,
+ *                                  default 30, 0 = never: 100-d float32 rows take 512 bytes = exactly four lines
+ *                                  instead of straddling four to five; zero padded, distances keep their bits)
  *   links   [n_nodes][M] uint32   (duplicate ids inside a row are replaced by the node's own id,
  *                                  which the search treats exactly like the reference treats an
  *                                  already-visited link)
@@ -92,8 +95,9 @@ int fnv_index_alloc(uint32_t M, uint64_t n_nodes, int data_type, int metric, uin
  * stream and options (copied from `src` at creation): lets callers keep several searches in flight on one index
  * (fnv_search_batch_device allows one launch in flight per handle).  Measured: back-to-back 10 000-query batches on two
  * handles / two streams run no faster than on one (7.72 M vs 7.65 M queries/s) -- the persistent grids do not overlap
- * usefully -- so this is a concurrency convenience, not a throughput lever.  The view does not follow later growth of
- * the source (it keeps the live node count it was created with); free it before the source. */
+ * usefully -- so this is a concurrency convenience, not a throughput lever.  The view reads the source's live node
+ * count at every launch (it follows fnv_index_set_live_nodes / fnv_index_insert_batch on the source); the source
+ * counts its views and fnv_index_free(source) fails with FNV_ERR_INVALID while any is alive: free views first. */
 int fnv_index_view(fnv_index_t src, fnv_index_t* out);
 
 /* Device pointers and byte sizes of the three index buffers: [0]=vectors [1]=links [2]=labels. */
@@ -169,6 +173,9 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *                     variant for the adaptive choice to measure (it tries 0, 50, 75 and 100); >= 0 = fixed
  *   "beam_registers"  != 0 (default): beams of at most 256 entries keep the sorted array in registers (the merge's
  *                     permutation goes through LDS); 0 = the array always lives in LDS, as it does for wider beams
+ *   "sorted_variant"  -1 (default) = the adaptive choice above; 0..4 = pin what a merged-beam-capable launch runs:
+ *                     0 two-heap kernel, 1 merged-beam kernel, 2 / 3 / 4 merged-beam kernel with the last 50 / 75 / 100 %
+ *                     of a round straight to the exact search (launches of one round or less run 1 instead)
  *   "sorted_beam_min" smallest beam width the merged-beam kernel is used for (default 1)
  *   "sorted_cand_lds" where the exact re-run of the merged-beam kernel keeps its candidates heap: 2 (default) = in LDS
  *                     when that costs neither resident queries nor visited-table slots, or -- beams of at most 128
@@ -211,9 +218,11 @@ int fnv_search_batch_device(fnv_index_t index, const void* d_queries, uint64_t n
  *   stream); free each with fnv_index_free.  One process drives all GPUs -- processes that own one GPU each
  *   (torch.distributed) broadcast the buffers of fnv_index_device_buffers with RCCL instead.
  * fnv_replica_refresh: copies the live rows of `src` into existing replicas again (after the source grew or was
- *   re-wired).
+ *   re-wired); replicas also take over the source's options (fnv_set_option) at every refresh.
  * fnv_search_batch_multi: fnv_search_batch over several handles of the same index: rows [g*ceil(Q/G), ...) go to
- *   indexes[g]; all devices work concurrently (per-device stream), results land in the caller's row ranges. */
+ *   indexes[g]; every shard is driven by its own host thread (staging copies, launch and wait of all devices
+ *   overlap), results land in the caller's row ranges.  The calling thread's current HIP device is left as it was
+ *   (by every entry point of this library). */
 int fnv_replicate(fnv_index_t src, int n_devices, const int* devices, fnv_index_t* out);
 int fnv_replica_refresh(fnv_index_t src, int n_replicas, fnv_index_t* replicas);
 int fnv_search_batch_multi(fnv_index_t* indexes, int n_indexes, const void* queries, uint64_t nq, int K,
@@ -238,6 +247,27 @@ int fnv_last_replayed_queries(fnv_index_t index, uint64_t out[5]);
  * kernel, 1 = merged-beam kernel with the beam in registers, 2 = with the beam in LDS, tail_exact: the last that-many queries of the launch
  * went straight to the exact search (merged-beam kernel, see the "sorted_tail_exact_pct" option)}. */
 int fnv_last_launch_geometry(fnv_index_t index, uint64_t geom[8]);
+
+/* The adaptive kernel choice ("sorted_beam" = 2) measures its variants on the caller's launches: up to 15 launches per
+ * (beam width, batch-size class) run a variant that is being sampled, not the final pick.  fnv_tune takes all those
+ * samples in ONE call -- every variant, a cold launch plus three timed ones, on the given batch (host pointer, or
+ * device pointer with queries_on_device != 0; results are discarded) -- so that the first launch afterwards with
+ * the same K / ef_search and a batch of the same class (more than one round of resident queries or not) already runs
+ * the final variant.  No-op when there is nothing to choose (pinned variant, non-adaptive mode, batches < 2048).
+ * There is no reference counterpart: the reference has one search routine (Index.h:606-707).
+ * fnv_last_launch_info: info[4] = {variant of the most recent launch (numbering of "sorted_variant"), 1 if that
+ * launch was an exploratory sample of the adaptive choice else 0, host steady-clock ns at which the most recent
+ * host-buffer search was enqueued, ... at which it completed (both 0 before the first one)}. */
+int fnv_tune(fnv_index_t index, const void* queries, uint64_t nq, int queries_on_device, int K, int ef_search,
+             int num_initializations);
+int fnv_last_launch_info(fnv_index_t index, uint64_t info[4]);
+
+/* Measurement aid (bench.py's roofline.gather_ceiling): GB/s of row bytes that a pure gather of random rows of this
+ * index's vector table reaches with the search kernel's own load pattern for this row width (lane groups, loads in
+ * flight) and `waves_per_cu` resident wavefronts per CU (0 = 16) -- the practical bound of the algorithmic rate for
+ * this (row bytes, table size): small tables are partly served by the 256 MiB Infinity Cache, rows that are not whole
+ * 128-byte lines pay for the lines they straddle.  About 20-40 ms of GPU time; no reference counterpart. */
+int fnv_gather_ceiling(fnv_index_t index, int waves_per_cu, double* gbps_out);
 
 #ifdef __cplusplus
 }

@@ -31,8 +31,29 @@ def test_single_gpu_line_has_the_contract_fields():
     assert d["config"]["recall_at_10"] >= 0.95 and "workload" in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["gather_ceiling"] > r["achieved"] > 0 and 0 < r["frac_of_gather_ceiling"] < 1  # pure gather beats gather + search
+    assert r["algorithmic_bytes_per_launch"] <= r["line_bytes_per_launch"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "100.00%" in c["sample"]  # GPU ids == CPU ids
+    assert "timed launches that were exploratory samples of the adaptive choice: 0" in d["config"]["kernel_choice"]
+
+
+def test_default_line_carries_the_other_configurations():
+    # the default invocation runs the further BASELINE configurations after the main one and reports each as a full
+    # entry under its own top-level key (here at test sizes: --secondary-index-size)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL +
+                         ["--secondary-configs", "c4,c5-lowrank", "--secondary-index-size", "50000"],
+                         capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["config"]["workload"].startswith("c2 ")
+    for name in ("c4", "c5-lowrank"):
+        e = d[name]
+        assert e["config"]["workload"].startswith(name + " ") and e["value"] > 0 and e["config"]["recall_at_10"] >= 0.95
+        assert e["roofline"]["algorithmic_bytes_per_launch"] > 0 and 0 < e["roofline"]["frac"] < 1
+        assert e["cpu_baseline"]["value"] > 0 and "GPU ids == CPU ids" in e["cpu_baseline"]["sample"]
+        assert any(x.get("config") == name and x["value"] == e["value"] for x in d["secondary"])
+    assert len(d["c4"]["ef_lines"]) == 4  # the fixed-ef sweep of c4
 
 
 def test_two_ranks_share_one_gpu_over_gloo():
@@ -78,7 +99,8 @@ def test_bench_spawns_its_own_ranks_and_runs_other_configs():
     assert out.returncode == 0, out.stderr[-3000:]
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 2 and d["config"]["workload"].startswith("c4 ") and d["value"] > 0
-    assert d["roofline"]["frac_of_achievable"] > d["roofline"]["frac"] > 0
+    assert d["roofline"]["frac_of_gather_ceiling"] > 0 and d["roofline"]["frac"] > 0  # (a 25 MB table gathers from L2: ceiling > HBM peak)
+    assert d["roofline"]["row_bytes"] == 400 and d["roofline"]["row_stride_bytes"] == 512  # 100-d rows on whole lines
 
 
 @pytest.mark.parametrize("metric", ["l2", "angular"])

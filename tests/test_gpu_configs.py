@@ -1,10 +1,12 @@
-"""The BASELINE.json configurations beyond C2 under -m gpu, at sizes the CPU oracle handles in seconds
-(the full sizes run through bench.py --config ...; FNV_FULLSIZE=1 raises the property tests below to them):
+"""The BASELINE.json configurations beyond C2 under -m gpu, at sizes the CPU oracle handles in seconds, and -- property
+tests at the bottom -- at their FULL sizes (10M x 768, 50M x 128) whenever the box can hold them (a GPU with >= 200 GB
+and >= 160 GB of host memory: the MI355X boxes; FNV_FULLSIZE=0 / 1 overrides the probe):
   C3  768-d float inner product on unit vectors (randn as worded, and the recall-qualified low-rank S3), M=32, ef=200
   C4  100-d unit vectors (GloVe stand-in), ef in {50, 100, 200, 400}: rows that are not a whole number of lane spans
   C5  128-d randn L2
-Float contract: distances within rtol 1e-5 (atol 1e-6 near zero), >= 99 % of queries with identical id
-lists -- against the oracle and against the oracle driving the reference's own compiled AVX-512 distance kernel."""
+Float contract: distances within rtol 1e-5 (atol 1e-6 near zero), >= 99.9 % of queries with identical id
+lists -- against the oracle and against the oracle driving the reference's own compiled AVX-512 distance
+kernel; the measured fraction is printed."""
 import os
 
 import numpy as np
@@ -13,7 +15,23 @@ import pytest
 from flatnav_amd import datasets as ds
 
 pytestmark = pytest.mark.gpu
-FULL = os.environ.get("FNV_FULLSIZE") == "1"
+ID_BAR = 0.999
+
+
+def _fullsize() -> bool:
+    """Run the property tests at 10M x 768 / 50M x 128?  FNV_FULLSIZE=0/1 decides; unset: yes when the GPU has >= 200 GB
+    and the host >= 160 GB of memory (node store 32 GB + the oracle's copy + staging)."""
+    env = os.environ.get("FNV_FULLSIZE")
+    if env is not None:
+        return env == "1"
+    try:
+        import psutil
+        import torch
+
+        return (torch.cuda.get_device_properties(0).total_memory >= 200 * 2 ** 30
+                and psutil.virtual_memory().available >= 160 * 2 ** 30)
+    except Exception:
+        return False
 
 
 @pytest.fixture(scope="module")
@@ -47,21 +65,22 @@ def _float_parity(oracle_mod, hipmod, ix, Q, K, ef, kernels=("default", "two_hea
         dev.set_option("sorted_beam", 0 if kern == "two_heaps" else 2)
         gd, gl, gst = dev.search(Q, K, ef, stats=True)
         same = (ol == gl).all(axis=1)
-        assert same.mean() >= 0.99, "%s: ids identical on only %.3f of the queries" % (kern, same.mean())
+        print("%s kernel, ef=%d: ids identical to the oracle on %.2f%% of %d queries" % (kern, ef, 100 * same.mean(), len(Q)))
+        assert same.mean() >= ID_BAR, "%s: ids identical on only %.4f of the queries" % (kern, same.mean())
         assert np.allclose(od[same], gd[same], rtol=1e-5, atol=1e-6)
         # same path through the graph <=> same counters
-        assert (ost["n_dist"][same] == gst["n_dist"][same]).mean() >= 0.99
+        assert (ost["n_dist"][same] == gst["n_dist"][same]).mean() >= ID_BAR
         assert (np.diff(gd, axis=1) >= 0).all() and (gst["count"] == K).all()
         if have_ref:
             same_r = (rl == gl).all(axis=1)
-            assert same_r.mean() >= 0.99
+            assert same_r.mean() >= ID_BAR, "%s vs reference distance kernel: %.4f" % (kern, same_r.mean())
             assert np.allclose(rd[same_r], gd[same_r], rtol=1e-5, atol=1e-6)
     return dev
 
 
 @pytest.mark.parametrize("kind", ["randn_unit", "lowrank_unit"])
 def test_c3_shape_768d_float_inner_product_ef200(oracle_mod, hipmod, kind):
-    N, NQ = (12000, 500) if kind == "randn_unit" else (20000, 1000)
+    N, NQ = (12000, 1000) if kind == "randn_unit" else (20000, 1000)
     if kind == "randn_unit":
         X, Q = ds.randn(N, NQ, 768, seed=768, normalize=True)
     else:
@@ -93,14 +112,16 @@ def test_c5_shape_128d_randn_l2(oracle_mod, hipmod):
 
 @pytest.mark.parametrize("config,n_small,n_full", [("c3-lowrank", 400_000, 10_000_000), ("c5", 2_000_000, 50_000_000)])
 def test_fullsize_properties(oracle_mod, config, n_small, n_full):
-    # Size-independent properties at (FNV_FULLSIZE=1) the configurations' own sizes, index built on the GPU from data
+    # Size-independent properties at the configurations' own sizes (see _fullsize), index built on the GPU from data
     # generated on the GPU: sortedness, exact recomputed distances for every returned id, idempotence across
-    # launches, and GPU == oracle on a 100-query sample of the same blob.
+    # launches, and GPU == oracle on a 1000-query sample of the same blob.
     import torch
 
     import flatnav_amd as flatnav
 
-    N = n_full if FULL else n_small
+    full = _fullsize()
+    N = n_full if full else n_small
+    print("%s at N = %d (%s)" % (config, N, "FULL SIZE" if full else "reduced: not enough GPU / host memory, or FNV_FULLSIZE=0"))
     dim, metric, ef = (768, "angular", 200) if config == "c3-lowrank" else (128, "l2", 100)
     NQ, K, M = 2000, 10, 32
     g = torch.Generator(device="cuda")
@@ -128,6 +149,7 @@ def test_fullsize_properties(oracle_mod, config, n_small, n_full):
     exact = ((rows - Q[:, None, :]) ** 2).sum(-1) if metric == "l2" else 1.0 - (rows * Q[:, None, :]).sum(-1)
     assert np.allclose(exact, d, rtol=1e-4, atol=1e-5)
     o = oracle_mod.OracleIndex.from_blob(metric, "float32", dim, N, N, M, blob.reshape(-1))
-    od, ol = o.search(Q[:100], K, ef, threads=8)
-    same = (ol == l[:100]).all(axis=1)
-    assert same.mean() >= 0.99 and np.allclose(od[same], d[:100][same], rtol=1e-5, atol=1e-6)
+    od, ol = o.search(Q[:1000], K, ef, threads=min(16, os.cpu_count() or 1))
+    same = (ol == l[:1000]).all(axis=1)
+    print("%s N=%d: ids identical to the oracle on %.2f%% of 1000 queries" % (config, N, 100 * same.mean()))
+    assert same.mean() >= ID_BAR and np.allclose(od[same], d[:1000][same], rtol=1e-5, atol=1e-6)

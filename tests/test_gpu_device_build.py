@@ -63,7 +63,7 @@ def test_device_build_matches_host_build_quality(flatnav, oracle_mod, dt, wiring
 
 
 def test_device_build_appends_to_an_existing_graph(flatnav, oracle_mod):
-    N, NQ, M, K = 12000, 300, 16, 10
+    N, NQ, M, K = 12000, 1000, 16, 10
     X, Q = ds.lowrank_normalized(N, NQ, 100, 24, 5)
     ix = flatnav.index.create("angular", 100, N, M, flatnav.data_type.DataType.float32)
     ix.set_num_threads(4)
@@ -78,7 +78,7 @@ def test_device_build_appends_to_an_existing_graph(flatnav, oracle_mod):
     assert ds.recall_at_k(l, lab[gt]) > 0.9
     o = oracle_mod.OracleIndex.from_blob("angular", "float32", 100, N, N, M, np.asarray(ix._raw_blob()))
     od, ol = o.search(Q, K, 100)
-    assert (ol == l).all(axis=1).mean() > 0.99  # float: rare rounding flips allowed, as in the other parity tests
+    assert (ol == l).all(axis=1).mean() >= 0.999  # float: rare rounding flips allowed, as in the other parity tests
     # a later host insertion invalidates the device copy again and still works
     with pytest.raises(RuntimeError):
         ix.add(X[:1], 64, device=True)  # full

@@ -1,8 +1,8 @@
 """GPU parity: the HIP search path (through the C ABI) against the CPU oracle on the same graphs.
 
 Bar: integer-valued data -> ids, distances, per-query counters BIT-EXACT, including
-tie-heavy inputs; float data -> distances within rtol 1e-5 (stated below), >= 99% of queries with
-identical id lists, recall identical to 3 decimals."""
+tie-heavy inputs; float data -> distances within rtol 1e-5 (stated below), >= 99.9% of queries with
+identical id lists (anything looser indicates a bug), recall identical to 3 decimals."""
 import numpy as np
 import pytest
 
@@ -100,14 +100,15 @@ def test_dimension_classes_integer_valued(oracle_mod, hipmod, dim, M):
 
 @pytest.mark.parametrize("metric", ["l2", "ip"])
 def test_float_data_within_tolerance(oracle_mod, hipmod, metric):
-    # Float contract: rtol 1e-5 on distances, >= 99% identical id lists, recall equal to 3 decimals.
+    # Float contract: rtol 1e-5 on distances, >= 99.9% identical id lists, recall equal to 3 decimals.
     X, Q = ds.randn(20000, 1000, 128, seed=3, normalize=(metric == "ip"))
     ix = _build(oracle_mod, metric, "float32", X, 32)
     dev = _upload(hipmod, ix)
     od, ol = ix.search(Q, 10, 100)
     gd, gl = dev.search(Q, 10, 100)
     same = (ol == gl).all(axis=1)
-    assert same.mean() >= 0.99
+    print("ids identical to the oracle on %.2f%% of %d queries (%s)" % (100 * same.mean(), len(Q), metric))
+    assert same.mean() >= 0.999
     # stated float tolerance: rtol 1e-5 (atol 1e-6 for inner-product distances near zero)
     assert np.allclose(od[same], gd[same], rtol=1e-5, atol=1e-6)
     worst = float(np.max(np.abs(od[same] - gd[same]) / np.maximum(np.abs(od[same]), 1e-3)))
@@ -119,7 +120,7 @@ def test_float_data_within_tolerance(oracle_mod, hipmod, metric):
     if ix.use_reference_distance(True):
         rd, rl = ix.search(Q, 10, 100)
         same_r = (rl == gl).all(axis=1)
-        assert same_r.mean() >= 0.99
+        assert same_r.mean() >= 0.999
         assert np.allclose(rd[same_r], gd[same_r], rtol=1e-5, atol=1e-6)
         print("ids identical to the reference-distance search on %.2f%% of queries" % (100 * same_r.mean()))
 

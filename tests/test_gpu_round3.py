@@ -1,0 +1,233 @@
+"""Round-3 additions to the C ABI, each against the oracle or against the library's own exact path:
+  * row stride on whole 128-byte lines (FLATNAV_ROW_PAD_PCT): every bit of every result unchanged;
+  * fnv_tune / "sorted_variant" / fnv_last_launch_info: the adaptive kernel choice settled in one call, no exploratory
+    launch afterwards, every pinned variant returns the oracle's bytes;
+  * views count on their source (free refused, growth followed); replicas take over the source's options;
+  * fnv_search_batch_multi drives every shard from its own host thread: the second handle's launch is enqueued before the
+    first one's search completes;
+  * fnv_gather_ceiling returns a plausible rate."""
+import os
+
+import numpy as np
+import pytest
+
+from flatnav_amd import datasets as ds
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hipmod():
+    from flatnav_amd import hip
+
+    assert hip.device_count() >= 1, "no MI355X visible"
+    return hip
+
+
+def _upload(hipmod, ix):
+    return hipmod.DeviceIndex.upload(ix.blob(), ix.node_size, ix.data_size, ix.M, ix.cur_nodes, ix.dtype, ix.metric, ix.dim)
+
+
+@pytest.mark.parametrize("dt,dim,metric", [("float32", 100, "angular"), ("uint8", 100, "l2"), ("float32", 200, "l2"),
+                                           ("int8", 37, "angular"), ("float32", 760, "l2")])
+def test_rows_on_whole_lines_keep_every_bit(oracle_mod, hipmod, dt, dim, metric, monkeypatch):
+    rng = np.random.default_rng(dim)
+    N, NQ = 6000, 400
+    if dt == "float32":
+        X = rng.standard_normal((N, dim), dtype=np.float32)
+        Q = rng.standard_normal((NQ, dim), dtype=np.float32)
+        if metric == "angular":
+            X /= np.linalg.norm(X, axis=1, keepdims=True)
+            Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    else:
+        lo, hi = (0, 40) if dt == "uint8" else (-20, 20)
+        X = rng.integers(lo, hi, (N, dim)).astype(dt)
+        Q = rng.integers(lo, hi, (NQ, dim)).astype(dt)
+    ix = oracle_mod.OracleIndex.create(metric, dim, N, 16, dt)
+    ix.add(X, 48, threads=8)
+    esize = 4 if dt == "float32" else 1
+    rb16 = (dim * esize + 15) // 16 * 16
+    rb128 = (rb16 + 127) // 128 * 128
+    monkeypatch.setenv("FLATNAV_ROW_PAD_PCT", "0")
+    plain = _upload(hipmod, ix)
+    assert plain.row_bytes == rb16
+    monkeypatch.delenv("FLATNAV_ROW_PAD_PCT")
+    padded = _upload(hipmod, ix)
+    assert padded.row_bytes == (rb128 if (rb128 - rb16) * 100 <= 30 * rb16 else rb16)
+    monkeypatch.setenv("FLATNAV_ROW_PAD_PCT", "400")
+    always = _upload(hipmod, ix)
+    assert always.row_bytes == rb128
+    cfg = [pick_cfg(dev.row_bytes // 16) for dev in (plain, padded, always)]
+    for ef in (30, 150):
+        for mode in (2, 0):
+            outs = []
+            for dev in (plain, padded, always):
+                dev.set_option("sorted_beam", mode)
+                outs.append(dev.search(Q, 10, ef, stats=True))
+            for i in (1, 2):
+                other = outs[i]
+                if dt != "float32" or cfg[i] == cfg[0]:
+                    # integer arithmetic, or the same lane-to-chunk mapping (the zero padding adds nothing to either
+                    # partial sum): the same bits
+                    assert np.array_equal(outs[0][0].view(np.uint32), other[0].view(np.uint32))
+                    assert np.array_equal(outs[0][1], other[1])
+                    assert all(np.array_equal(outs[0][2][k], other[2][k]) for k in ("count", "n_dist", "n_hops"))
+                else:  # another row configuration sums the same products in another order: float tolerance
+                    same = (outs[0][1] == other[1]).all(axis=1)
+                    assert same.mean() >= 0.99 and np.allclose(outs[0][0][same], other[0][same], rtol=1e-5, atol=1e-6)
+    if dt != "float32":  # integer data: also bit-exact against the oracle in every layout
+        od, ol, ost = ix.search(Q, 10, 150, stats=True)
+        for dev in (plain, padded, always):
+            gd, gl, gst = dev.search(Q, 10, 150, stats=True)
+            assert np.array_equal(ol, gl) and np.array_equal(od.view(np.uint32), gd.view(np.uint32))
+            assert np.array_equal(ost["n_dist"], gst["n_dist"])
+
+
+def pick_cfg(nchunks):
+    """csrc/kernel_table.h pick_row_cfg."""
+    cfgs = [8, 16, 32, 64, 128, 256]
+    if nchunks > 128 and nchunks % 192 == 0:
+        return 6
+    for c, span in enumerate(cfgs):
+        if span >= nchunks:
+            return c
+    return 5
+
+
+def test_tune_settles_the_kernel_choice_and_variants_can_be_pinned(oracle_mod, hipmod):
+    X, Q = ds.sift_like(30000, 6000)  # integer-valued: ties -> the variants differ in speed, never in results
+    ix = oracle_mod.OracleIndex.create("l2", 128, 30000, 16)
+    ix.add(X, 64, threads=8)
+    want = ix.search(Q, 10, 64, stats=True)
+    dev = _upload(hipmod, ix)
+    # without tuning, the first big launches of a beam width are exploratory samples
+    dev.search(Q, 10, 64)
+    assert dev.launch_info()["exploratory"]
+    dev.set_option("sorted_beam", 2)  # resets what has been measured
+    dev.tune(Q, 10, 64)
+    finals = set()
+    for _ in range(6):
+        got = dev.search(Q, 10, 64, stats=True)
+        info = dev.launch_info()
+        assert not info["exploratory"]
+        finals.add(info["variant_id"])
+        assert np.array_equal(want[1], got[1]) and np.array_equal(want[0].view(np.uint32), got[0].view(np.uint32))
+        assert np.array_equal(want[2]["n_dist"], got[2]["n_dist"])
+    assert len(finals) == 1  # the first launch after fnv_tune already runs the final variant, and so does every later one
+    # another beam width has not been measured yet
+    dev.search(Q, 10, 40)
+    assert dev.launch_info()["exploratory"]
+    # device-resident queries
+    import torch
+
+    dq = torch.from_numpy(Q).cuda()
+    dev.tune(int(dq.data_ptr()), 10, 40, nq=len(Q))
+    dev.search(Q, 10, 40)
+    assert not dev.launch_info()["exploratory"]
+    # every variant pinned: same bytes as the oracle
+    slots = dev.launch_geometry()["blocks_per_cu"] * 256
+    for v in range(5):
+        dev.set_option("sorted_variant", v)
+        got = dev.search(Q, 10, 64, stats=True)
+        info = dev.launch_info()
+        assert not info["exploratory"] and (info["variant_id"] == v or (v >= 2 and len(Q) <= slots))
+        assert np.array_equal(want[1], got[1]) and np.array_equal(want[0].view(np.uint32), got[0].view(np.uint32))
+        assert all(np.array_equal(want[2][k], got[2][k]) for k in ("count", "n_dist", "n_hops"))
+    with pytest.raises(ValueError):
+        dev.set_option("sorted_variant", 5)
+    with pytest.raises(ValueError):
+        dev.tune(Q[:0], 10, 64)
+
+
+def test_views_count_on_their_source(oracle_mod, hipmod):
+    X, Q = ds.sift_like(8000, 300)
+    ix = oracle_mod.OracleIndex.create("l2", 128, 8000, 16)
+    ix.add(X[:4000], 48)
+    half_blob = np.array(ix.blob()[: 4000 * ix.node_size], copy=True)
+    want_half = ix.search(Q, 10, 50, stats=True)
+    ix.add(X[4000:], 48, labels=np.arange(4000, 8000))
+    want_full = ix.search(Q, 10, 50, stats=True)
+    # a source that is still growing: capacity 8000, the first 4000 nodes live
+    src = hipmod.DeviceIndex.alloc(16, 8000, "float32", "l2", 128)
+    src.write_nodes(0, half_blob, ix.node_size, ix.data_size)
+    src.set_live_nodes(4000)
+    view = src.view()
+    second = view.view()  # a view of a view hangs off the owner
+    with pytest.raises(ValueError, match="live views"):
+        src.close()
+    for h in (src, view, second):
+        got = h.search(Q, 10, 50, stats=True)
+        assert np.array_equal(want_half[1], got[1]) and np.array_equal(want_half[0], got[0])
+    # the source grows: the views read its live node count at every launch
+    src.write_nodes(0, np.asarray(ix.blob()), ix.node_size, ix.data_size)
+    src.set_live_nodes(8000)
+    for h in (src, view, second):
+        got = h.search(Q, 10, 50, stats=True)
+        assert np.array_equal(want_full[1], got[1]) and np.array_equal(want_full[0], got[0])
+        assert np.array_equal(want_full[2]["n_dist"], got[2]["n_dist"])
+    second.close()
+    view.close()
+    src.close()  # now it goes
+
+
+def test_replicas_take_over_the_sources_options(oracle_mod, hipmod):
+    X, Q = ds.sift_like(8000, 1000)
+    ix = oracle_mod.OracleIndex.create("l2", 128, 8000, 16)
+    ix.add(X, 48, labels=np.arange(8000) + 500000, threads=8)
+    src = _upload(hipmod, ix)
+    src.set_option("output_node_ids", 1)
+    src.set_option("sorted_beam", 0)
+    ids = src.search(Q, 10, 50)
+    assert ids[1].max() < 8000
+    reps = src.replicate([0, 0])
+    got = hipmod.search_multi([src] + reps, Q, 10, 50)
+    assert np.array_equal(got[1], ids[1]) and np.array_equal(got[0], ids[0])
+    for r in reps:
+        r.search(Q[:200], 10, 50)
+        assert r.launch_geometry()["kernel"] == "two_heaps"
+    # options changed later reach the replicas with the next refresh; until then a mixed batch is refused
+    src.set_option("output_node_ids", 0)
+    with pytest.raises(ValueError, match="output_node_ids"):
+        hipmod.search_multi([src] + reps, Q, 10, 50)
+    src.refresh_replicas(reps)
+    got = hipmod.search_multi([src] + reps, Q, 10, 50)
+    assert got[1].min() >= 500000 and np.array_equal(got[1] - 500000, ids[1])
+
+
+def test_multi_handle_search_overlaps_its_shards(oracle_mod, hipmod):
+    import torch
+
+    X, Q = ds.sift_like(40000, 40000)
+    ix = oracle_mod.OracleIndex.create("l2", 128, 40000, 16)
+    ix.add(X, 48, threads=8)
+    src = _upload(hipmod, ix)
+    rep = src.replicate([0])[0]
+    before = torch.cuda.current_device()
+    want = src.search(Q, 10, 200)
+    hipmod.search_multi([src, rep], Q, 10, 200)  # warm: workspaces, plans
+    overlapped = 0
+    for _ in range(5):
+        got = hipmod.search_multi([src, rep], Q, 10, 200)
+        a, b = src.launch_info(), rep.launch_info()
+        # each shard (20 000 queries, 5 MB of pageable queries, several ms of kernel) is enqueued before the other completes
+        overlapped += 1 if (b["enqueued_ns"] < a["completed_ns"] and a["enqueued_ns"] < b["completed_ns"]) else 0
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0])
+    assert overlapped >= 4, overlapped
+    assert torch.cuda.current_device() == before
+
+
+def test_gather_ceiling_is_a_plausible_rate(oracle_mod, hipmod):
+    import flatnav_amd as flatnav
+
+    X, _ = ds.sift_like(400_000, 10)
+    index = flatnav.index.create("l2", 128, len(X), 16)
+    index.set_num_threads(min(16, os.cpu_count() or 1))
+    index.add(X, 32, device=True)
+    import ctypes
+
+    dev = hipmod.DeviceIndex(ctypes.c_void_p(index.device_handle()), owned=False)
+    rate = dev.gather_ceiling()
+    print("gather ceiling on a 205 MB table of 512-byte rows: %.0f GB/s" % rate)
+    assert 2000 < rate < 16000  # an Infinity-Cache-resident table may exceed the HBM peak
+    d, l = index.search(X[:100], 1, 50)
+    assert (l[:, 0] == np.arange(100)).mean() > 0.95  # the measurement left the index intact
