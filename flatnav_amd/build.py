@@ -69,7 +69,7 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str | Non
         return LIB
     objdir = OBJ if not custom else OBJ + "_" + "_".join(sorted(d.replace("=", "-") for d in defines))[:80]
     os.makedirs(objdir, exist_ok=True)
-    base = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+    base = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
             "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include")]
     if verbose:
         base.insert(1, "-Rpass-analysis=kernel-resource-usage")

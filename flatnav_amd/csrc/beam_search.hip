@@ -206,9 +206,12 @@ struct IndexOptions {
           cand_slots = 0, spill_entries = 16384, blocks_per_cu = 0, visited_wide = 0,
           entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0, sorted_beam = 2,
           sorted_beam_min = 1, sorted_cand_lds = 2, sorted_tail_exact_pct = -1, beam_registers = 1,
-          sorted_variant = -1;
+          sorted_variant = -1, tune_layout = 1;
   int64_t overflow_list = -1;  // -1: automatic (a list in HBM only when the bitmap is larger than 512 KB)
 };
+
+constexpr int kNumVariants = 6;
+static const int kTailPct[kNumVariants] = {0, 0, 50, 75, 100, 25};
 
 struct fnv_index_s : IndexOptions {
   bool owns_buffers = true;  // false: a view (fnv_index_view) of another handle's vectors / links / labels
@@ -227,11 +230,17 @@ struct fnv_index_s : IndexOptions {
   LaunchPlan plan;
   // adaptive kernel choice ("sorted_beam" = 2): per beam width, the best time per query seen for each variant
   struct Tuner {
-    // ms per query: [0] two-heap kernel, [1] merged-beam kernel, [2..4] merged-beam kernel whose last 50 / 75 / 100 %
+    // ms per query: [0] two-heap kernel, [1] merged-beam kernel, [2..5] merged-beam kernel whose last 50 / 75 / 100 / 25 %
     // of a round of queries go straight to the exact search ("sorted_tail_exact_pct"; launches of more than one round)
-    float best[5] = {-1.f, -1.f, -1.f, -1.f, -1.f};
-    int samples[5] = {0, 0, 0, 0, 0};
+    float best[kNumVariants] = {-1.f, -1.f, -1.f, -1.f, -1.f, -1.f};
+    int samples[kNumVariants] = {0, 0, 0, 0, 0, 0};
   };
+  // Per beam width: the LDS layout fnv_tune measured to be the fastest (absent: the rules of configure_launch).
+  struct LayoutChoice {
+    int cand_lds = -1;       // where the exact search keeps its candidates heap: -1 = by rule, 0 = HBM, 1 = LDS
+    uint32_t vis_slots = 0;  // visited-table slots: 0 = by rule
+  };
+  std::map<int, LayoutChoice> layouts;
   std::map<int, Tuner> tuner;
   int sample_B = 0, sample_kernel = -1;  // the launch between ev0 / ev1 is a sample for this entry (-1: it is not)
   int force_variant = -1;                // fnv_tune: the variant the next launch must run (-1: none)
@@ -605,13 +614,15 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   else if (n == "sorted_tail_exact_pct") ix->sorted_tail_exact_pct = value;
   else if (n == "beam_registers") ix->beam_registers = value;
   else if (n == "sorted_variant") {
-    if (value > 4) return fail(FNV_ERR_INVALID, "sorted_variant must be -1 (adaptive) or 0..4");
+    if (value >= kNumVariants) return fail(FNV_ERR_INVALID, "sorted_variant must be -1 (adaptive) or 0..5");
     ix->sorted_variant = value;
   }
   else if (n == "visited_tag_bits") ix->visited_tag_bits = value;
+  else if (n == "tune_layout") ix->tune_layout = value;
   else return fail(FNV_ERR_INVALID, "unknown option: " + n);
   ix->options_version++;
   ix->tuner.clear();
+  ix->layouts.clear();
   ix->sample_kernel = -1;
   return FNV_OK;
 }
@@ -695,7 +706,7 @@ static uint32_t lay_out(const fnv_index_s* ix, SearchParams& p, uint32_t slots, 
 // part of the ids to the HBM bitmap (measured: profiles/r1_visited_sizing.md).  So: the largest size <= roomy that
 // still leaves `occupancy_target` queries per CU, but never below visited_floor slots.
 static int configure_launch(fnv_index_s* ix, SearchParams& p, kernel_fn kern, int mode, uint32_t* lds_out, int* bpc_out,
-                            bool grow_free = true) {
+                            bool grow_free = true, uint32_t forced_slots = 0) {
   auto resident = [&](uint32_t lds) -> int {  // query slots one CU can hold with this much LDS each
     if (lds > 160u * 1024u) return 0;
     int n = 0;
@@ -703,8 +714,9 @@ static int configure_launch(fnv_index_s* ix, SearchParams& p, kernel_fn kern, in
     return n;
   };
   uint32_t lds_bytes;
-  if (ix->visited_slots) {
-    lds_bytes = lay_out(ix, p, (uint32_t)ix->visited_slots, mode);
+  if (forced_slots == 0) forced_slots = (uint32_t)ix->visited_slots;
+  if (forced_slots) {
+    lds_bytes = lay_out(ix, p, forced_slots, mode);
   } else {
     const uint64_t want = std::max<uint64_t>((uint64_t)ix->visited_factor * (uint64_t)p.B + 600, 256);
     std::vector<uint32_t> sizes;
@@ -830,34 +842,39 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     plan.mode = (!tagged || !want) ? MODE_HEAPS : (B <= MB_MAX_BEAM && ix->beam_registers != 0) ? MODE_MERGED_REGS : MODE_MERGED_LDS;
     if (plan.mode != MODE_HEAPS) {
       plan.skern = pick_sorted_kernel(ix->dtype, ix->metric, cfg, full, plan.mode == MODE_MERGED_LDS, B);
+      // a layout that fnv_tune measured for this beam width overrides the rules below (heap home, table size)
+      fnv_index_s::LayoutChoice lc;
+      if (auto it = ix->layouts.find(B); it != ix->layouts.end()) lc = it->second;
+      const int64_t cand_lds_mode = lc.cand_lds >= 0 ? lc.cand_lds : ix->sorted_cand_lds;
+      const uint32_t forced = lc.vis_slots;
       // the exact re-run's candidates heap: in LDS if that costs neither resident queries nor visited-table
       // slots, else entirely in the slot's HBM spill area (slower for the few queries that need it)
       SearchParams with = p, without = p;
       without.cand_slots = 0;
       uint32_t lds_w = 0, lds_wo = 0;
       int bpc_w = 0, bpc_wo = 0;
-      rc = configure_launch(ix, without, plan.skern, plan.mode, &lds_wo, &bpc_wo, false);
+      rc = configure_launch(ix, without, plan.skern, plan.mode, &lds_wo, &bpc_wo, false, forced);
       if (rc) return rc;
-      const int rc_w = configure_launch(ix, with, plan.skern, plan.mode, &lds_w, &bpc_w, false);
+      const int rc_w = configure_launch(ix, with, plan.skern, plan.mode, &lds_w, &bpc_w, false, forced);
       // (an exact re-run whose candidates heap lives in HBM pays a global round trip per heap operation: a handful of
       // such queries per launch are stragglers that cost 10 % of it -- measured at ef=100 on float data with 5 re-runs
       // in 10 000 queries -- so up to beams of 128 the LDS home is worth going down to 9 resident queries; wider beams'
       // heaps cost more LDS than the stragglers cost time)
-      bool keep_lds = rc_w == FNV_OK && (ix->sorted_cand_lds == 1 ||
-                                         (ix->sorted_cand_lds == 2 && ((bpc_w >= bpc_wo && with.vis_slots >= without.vis_slots) ||
-                                                                       (B <= 2 * WAVE && bpc_w >= (int)ix->occupancy_roomy))));
+      bool keep_lds = rc_w == FNV_OK && (cand_lds_mode == 1 ||
+                                         (cand_lds_mode == 2 && ((bpc_w >= bpc_wo && with.vis_slots >= without.vis_slots) ||
+                                                                 (B <= 2 * WAVE && bpc_w >= (int)ix->occupancy_roomy))));
       // both candidates once more with the free table growth; an LDS home that costs residency AND table slots is not taken
       SearchParams fin_w = p, fin_wo = p;
       fin_w.cand_slots = with.cand_slots;
       fin_wo.cand_slots = 0u;
       uint32_t flds_w = 0, flds_wo = 0;
       int fbpc_w = 0, fbpc_wo = 0;
-      rc = configure_launch(ix, fin_wo, plan.skern, plan.mode, &flds_wo, &fbpc_wo);
+      rc = configure_launch(ix, fin_wo, plan.skern, plan.mode, &flds_wo, &fbpc_wo, true, forced);
       if (rc) return rc;
       if (keep_lds) {
-        rc = configure_launch(ix, fin_w, plan.skern, plan.mode, &flds_w, &fbpc_w);
+        rc = configure_launch(ix, fin_w, plan.skern, plan.mode, &flds_w, &fbpc_w, true, forced);
         if (rc) return rc;
-        if (ix->sorted_cand_lds == 2 && fin_w.vis_slots < fin_wo.vis_slots && fbpc_w < fbpc_wo) keep_lds = false;
+        if (cand_lds_mode == 2 && fin_w.vis_slots < fin_wo.vis_slots && fbpc_w < fbpc_wo) keep_lds = false;
       }
       plan.sorted = keep_lds ? fin_w : fin_wo;
       plan.slds = keep_lds ? flds_w : flds_wo;
@@ -886,7 +903,6 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   const uint64_t round_slots = (uint64_t)plan.sbpc * (uint64_t)ix->num_cus;
   const bool multi_round = sorted && nq > round_slots;
   int64_t tail_pct = ix->sorted_tail_exact_pct < 0 ? 0 : ix->sorted_tail_exact_pct;
-  static const int kTailPct[5] = {0, 0, 50, 75, 100};
   bool exploratory = false;
   const int pinned = ix->force_variant >= 0 ? ix->force_variant : (int)ix->sorted_variant;  // fnv_tune / "sorted_variant"
   if (sorted && pinned >= 0) {
@@ -909,9 +925,9 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
       const bool try_tail = multi_round && ix->sorted_tail_exact_pct < 0;
       // three samples each (the first launch of a kernel is a cold one; the best of the rest decides), then the fastest
       // (fnv_tune takes all the samples in one call, so that no caller's launch is an exploratory one)
-      const int nvar = try_tail ? 5 : 2;
+      const int nvar = try_tail ? kNumVariants : 2;
       variant = -1;
-      for (int v : {1, 0, 4, 3, 2})
+      for (int v : {1, 0, 4, 3, 2, 5})
         if (v < nvar && variant < 0 && t.samples[v] < 3) variant = v;
       exploratory = variant >= 0;
       if (variant < 0) {
@@ -1271,43 +1287,117 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
   const size_t o_lab = (size_t)nq * K * 4, obytes = 2 * o_lab;
   {
     std::lock_guard<std::mutex> lock(ix->mu);
-    int rc = queries_on_device ? FNV_OK : grow(&ix->d_q, &ix->d_q_bytes, qbytes);
+    int rc = grow(&ix->d_q, &ix->d_q_bytes, 2 * qbytes);
     if (!rc) rc = grow(&ix->d_out, &ix->d_out_bytes, obytes);
     if (rc) return rc;
   }
-  const void* dq = queries;
-  if (!queries_on_device) {
-    HIP_TRY(hipMemcpy(ix->d_q, queries, qbytes, hipMemcpyHostToDevice));
-    dq = ix->d_q;
-  }
+  // The batch twice in a row: a launch on rows [off, off + nq) searches the same queries in a rotated order.  Which
+  // queries tie -- and so which ones are stragglers of the last round -- is a property of the queries: timing several
+  // rotations and averaging measures a variant's EXPECTED time, not its luck with one order.
+  uint8_t* dq2 = (uint8_t*)ix->d_q;
+  HIP_TRY(hipMemcpy(dq2, queries, qbytes, queries_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dq2 + qbytes, dq2, qbytes, hipMemcpyDeviceToDevice));
+  const size_t qrow_bytes = (size_t)ix->dim * dtype_size(ix->dtype);
   uint8_t* o = (uint8_t*)ix->d_out;
-  auto launch = [&](int variant) -> int {
+  auto launch = [&](int variant, uint64_t rotate = 0) -> int {
     ix->force_variant = variant;
-    const int rc = search_device_impl(ix, dq, nq, K, ef_search, num_initializations, (float*)o, (int32_t*)(o + o_lab), nullptr,
-                                      nullptr, nullptr, ix->stream, ix->output_node_ids != 0);
+    const int rc = search_device_impl(ix, dq2 + (rotate % nq) * qrow_bytes, nq, K, ef_search, num_initializations, (float*)o,
+                                      (int32_t*)(o + o_lab), nullptr, nullptr, nullptr, ix->stream, ix->output_node_ids != 0);
     ix->force_variant = -1;
     return rc;
   };
   // what kind of launch is this?  (one probing launch of the merged-beam kernel tells: plan, round size)
+  const int B = std::max(ef_search, K);
+  {
+    std::lock_guard<std::mutex> lock(ix->mu);
+    ix->layouts.erase(B);
+    ix->tuner.erase(2 * B);
+    ix->tuner.erase(2 * B + 1);
+    ix->plan.valid = false;
+  }
   int rc = launch(1);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(ix->stream));
   if (ix->geom[6] == MODE_HEAPS || ix->sorted_beam != 2 || ix->sorted_variant >= 0 || nq < 2048) return FNV_OK;  // nothing to choose
-  const int B = std::max(ef_search, K);
-  const bool multi_round = nq > (uint64_t)ix->plan.sbpc * (uint64_t)ix->num_cus;
-  const int nvar = (multi_round && ix->sorted_tail_exact_pct < 0) ? 5 : 2;
-  fnv_index_s::Tuner t;
-  for (int v = 0; v < nvar; v++) {
-    for (int rep = 0; rep < 4; rep++) {
-      rc = launch(v);
-      if (rc) return rc;
+  // mean of `reps` timed launches of one variant, each on another rotation of the batch (after a cold launch), ms per query
+  auto time_variant = [&](int v, int reps, float* out) -> int {
+    float sum = 0.f;
+    for (int rep = 0; rep <= reps; rep++) {
+      const int r = launch(v, rep == 0 ? 0 : (uint64_t)(rep - 1) * nq / (uint64_t)reps);
+      if (r) return r;
       HIP_TRY(hipStreamSynchronize(ix->stream));
       float ms = 0.f;
       HIP_TRY(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
-      const float per_q = ms / (float)nq;
-      if (rep > 0 && (t.samples[v] == 0 || per_q < t.best[v])) t.best[v] = per_q;  // the first launch of a kernel is a cold one
-      if (rep > 0) t.samples[v]++;
+      if (rep > 0) sum += ms;  // the first launch of a kernel is a cold one
     }
+    *out = sum / (float)reps / (float)nq;
+    return FNV_OK;
+  };
+
+  // ---- 1. the LDS layout ------------------------------------------------------------------------------------------
+  // Resident queries, visited-table slots and the LDS home of the exact search's candidates heap trade against each
+  // other, and which trade wins depends on the data (how often queries tie, how many ids a query visits): rules cover
+  // the common cases (configure_launch), this measures the neighbours of the rule's choice -- heap home flipped, the
+  // table one size up / down -- with the merged-beam kernel alone and with its whole last round straight to the exact
+  // search, and keeps the fastest.  Skipped for whatever the caller pinned with an option.
+  const uint32_t base_slots = (uint32_t)ix->geom[4];
+  const bool base_heap_lds = ix->geom[5] != 0;
+  std::vector<fnv_index_s::LayoutChoice> cands(1);  // [0]: the rules
+  if (ix->tune_layout && ix->sorted_cand_lds == 2) {
+    fnv_index_s::LayoutChoice c;
+    c.cand_lds = base_heap_lds ? 0 : 1;
+    cands.push_back(c);
+  }
+  if (ix->tune_layout && ix->visited_slots == 0 && base_slots >= 512) {
+    const bool pow2 = (base_slots & (base_slots - 1)) == 0;
+    const uint32_t up = pow2 ? base_slots / 2 * 3 : base_slots / 3 * 4, down = pow2 ? base_slots / 4 * 3 : base_slots / 3 * 2;
+    for (uint32_t slots : {up, down}) {
+      if (slots < 256 || slots > (1u << 15)) continue;
+      fnv_index_s::LayoutChoice c;
+      c.vis_slots = slots;
+      cands.push_back(c);
+      if (ix->sorted_cand_lds == 2) {
+        c.cand_lds = base_heap_lds ? 0 : 1;
+        cands.push_back(c);
+      }
+    }
+  }
+  size_t best_layout = 0;
+  float best_layout_t = -1.f;
+  for (size_t li = 0; li < cands.size(); li++) {
+    {
+      std::lock_guard<std::mutex> lock(ix->mu);
+      if (li == 0) ix->layouts.erase(B);
+      else ix->layouts[B] = cands[li];
+      ix->plan.valid = false;
+    }
+    float t1 = -1.f, t4 = -1.f;
+    if (time_variant(1, 4, &t1) != FNV_OK) continue;  // e.g. a layout that does not fit LDS: not a candidate
+    const bool multi = nq > (uint64_t)ix->plan.sbpc * (uint64_t)ix->num_cus;
+    if (multi && ix->sorted_tail_exact_pct < 0 && time_variant(3, 4, &t4) != FNV_OK) continue;
+    const float t = (t4 > 0.f && t4 < t1) ? t4 : t1;
+    if (best_layout_t < 0.f || t < best_layout_t * 0.98f) {  // a neighbour must win by more than noise
+      best_layout_t = t;
+      best_layout = li;
+    }
+  }
+  {
+    std::lock_guard<std::mutex> lock(ix->mu);
+    if (best_layout == 0) ix->layouts.erase(B);
+    else ix->layouts[B] = cands[best_layout];
+    ix->plan.valid = false;
+  }
+  rc = launch(1);  // re-plan with the chosen layout
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+
+  // ---- 2. the kernel variant on that layout --------------------------------------------------------------------------
+  const bool multi_round = nq > (uint64_t)ix->plan.sbpc * (uint64_t)ix->num_cus;
+  const int nvar = (multi_round && ix->sorted_tail_exact_pct < 0) ? kNumVariants : 2;
+  fnv_index_s::Tuner t;
+  for (int v = 0; v < nvar; v++) {
+    rc = time_variant(v, 4, &t.best[v]);
+    if (rc) return rc;
     t.samples[v] = 4;  // settled: later launches neither explore nor sample
   }
   {

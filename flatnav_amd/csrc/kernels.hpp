@@ -231,7 +231,7 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, int qi, uint32_t 
   } else {
     visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), vg, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
   }
-  ovf = __ballot(ovf) != 0ull;
+  // (ovf is wave-uniform: the visited inserts set it for every lane)
   int err = ST_OK;
   uint32_t n_dist = 0, n_hops = 0;
   if (cand_slots == 0) __threadfence_block();
@@ -282,7 +282,6 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, int qi, uint32_t 
           }
         }
       }
-      ovf = __ballot(ovf) != 0ull;  // wave-uniform
       const unsigned long long newmask = __ballot(isnew);
       const int n = __popcll(newmask);
       stage_ids[isnew ? __popcll(newmask & ((1ull << lane) - 1ull)) : WAVE] = id;  // keeps link order; slot 64 = bin

@@ -65,6 +65,13 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
+// v with lane `l` (wave-uniform) replaced by the wave-uniform value s: one v_writelane_b32.  gfx950 reads at most one
+// scalar register per vector instruction, so the lane select travels in M0 (which nothing else in these kernels uses).
+__device__ __forceinline__ int writelane_i(int v, int s, int l) {
+  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(s), "s"(l) : "m0");
+  return v;
+}
+
 constexpr uint32_t EXPANDED_BIT = 0x80000000u;  // beam entries: id in bits 0-30 (the host checks capacity < 2^31)
 constexpr int NO_ENTRY = 1 << 30;               // LDS form: "no unexpanded entry" (compares >= every beam size)
 
@@ -164,7 +171,6 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : FNV_SORTED_WAVES_PER_SIMD) void
     bool ovf = false;
     if (vg.w == 16) visited_insert_tag16(vis, vg, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
     else visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), vg, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
-    ovf = __ballot(ovf) != 0ull;
     int tie = best_d != best_d ? 4 : 0;
     if ((uint32_t)qi + ca->tail_exact >= ca->nq) tie = 5;  // last round of the launch: straight to the exact search
     float amb = INF;    // (a) pending: key at which the reference's eviction choice is unknown
@@ -239,20 +245,20 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : FNV_SORTED_WAVES_PER_SIMD) void
       const uint32_t row0 = lane < M ? links[(uint64_t)(uint32_t)node * (uint32_t)M + lane] : EMPTY_ID;
       PH_MARK(3);
 
-      for (int m0 = 0; m0 < M; m0 += WAVE) {
+      // One 64-link chunk of the row: visited test-and-mark, gather + distances of the new ones, merge.  Returns false
+      // when the query has to be handed to the exact search (tie is set).  Rows of at most 64 links -- every
+      // configuration of the benchmark -- are ONE call on the straight path of the hop loop; wider rows loop below.
+      auto row_chunk = [&](const int m0, const uint32_t id) -> bool {
         const bool act = m0 + lane < M;
-        uint32_t id = row0;
-        if (m0 > 0) id = act ? links[(uint64_t)(uint32_t)node * (uint32_t)M + m0 + lane] : EMPTY_ID;
         bool isnew;
         if (vg.w == 16) isnew = visited_insert_tag16(vis, vg, act, id, bitmap, ovf_list, ovf_glist, ovf);
         else isnew = visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), vg, act, id, bitmap, ovf_list, ovf_glist, ovf);
-        ovf = __ballot(ovf) != 0ull;
         const unsigned long long newmask = __ballot(isnew);
         const int nn = __popcll(newmask);
         stage_ids[isnew ? __popcll(newmask & ((1ull << lane) - 1ull)) : WAVE] = id;  // keeps link order
         wave_sync();
         PH_MARK(4);
-        if (nn == 0) continue;
+        if (nn == 0) return true;
         n_dist += nn;
 
         // ---- distances of the row's unvisited neighbours, staged in link order ----------------------------------
@@ -277,26 +283,29 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : FNV_SORTED_WAVES_PER_SIMD) void
         PH_MARK(5);
 
         // ---- merge (see the header) ----------------------------------------------------------------------------
+        // Wave votes are taken on plain comparisons and combined as lane masks in scalar registers (a vote on a
+        // compound condition costs two more vector instructions: the compiler materialises the boolean first).
         const float d = stage_d[lane] + 0.0f;  // lane j: j-th neighbour in link order (-0 -> +0 for float_ord)
         const uint32_t cand_id = stage_ids[lane];
         const bool full0 = n >= B;
-        const bool pass = lane < nn && (!full0 || d < max_dist);  // superset of what one-by-one admission lets in
-        const unsigned long long pm = __ballot(pass);
+        const unsigned long long nnmask = nn >= WAVE ? ~0ull : (1ull << nn) - 1ull;  // lanes that hold a neighbour
+        // superset of what one-by-one admission lets in
+        const unsigned long long pm = (full0 ? __ballot(d < max_dist) : ~0ull) & nnmask;
         // (b) while a selection tie is pending the order of the tied expansions is the reference's choice; a neighbour
         // refused exactly at the cut (d == max_dist) would have been kept had its row come first
-        if (pend > -INF && full0 && __ballot(lane < nn && d == max_dist) != 0ull) pend_cut = true;
+        if (pend > -INF && full0 && (__ballot(d == max_dist) & nnmask) != 0ull) pend_cut = true;
         if (pm != 0ull) {
-          if (__ballot(pass && !(d < INF)) != 0ull) {  // NaN / infinite distance that could be admitted
+          if ((__ballot(!(d < INF)) & pm) != 0ull) {  // NaN / infinite distance that could be admitted
             tie = 4;
-            break;
+            return false;
           }
+          const bool pass = ((pm >> lane) & 1ull) != 0ull;
           const int c = __popcll(pm);
           const unsigned long long key64 = ((unsigned long long)float_ord(d) << 32) | (uint32_t)lane;
           uint32_t rank = 0;   // candidate lane: candidates that precede it in (key, link order)
           int bpos = 0;        // candidate lane: beam keys <= its key
           const int n_new = min(B, n + c);
-          bool out_eq = false;  // this lane holds an element left outside the new beam, (smallest) key out_key
-          float out_key = INF;
+          float out_key = INF;  // smallest key among the elements this lane leaves outside the new beam (+inf: none)
           if constexpr (R > 0) {
             uint32_t le[R];  // beam lane: candidates whose key is >= the entry's key (they go after it)
 #pragma unroll
@@ -310,13 +319,13 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : FNV_SORTED_WAVES_PER_SIMD) void
               int cnt = 0;
 #pragma unroll
               for (int r = 0; r < R; r++) {
-                if (r * WAVE < n) {  // wave-uniform
+                if (r == 0 || r * WAVE < n) {  // wave-uniform (chunk 0 always holds entries)
                   const bool b = kr[r] <= di;  // entries beyond n hold +inf
                   cnt += __popcll(__ballot(b));
                   le[r] += b ? 1u : 0u;
                 }
               }
-              bpos = lane == i ? cnt : bpos;
+              bpos = writelane_i(bpos, cnt, i);  // lane i keeps its own count
             }
             const int fpos = bpos + (int)rank;  // candidate's position in the stable merge
             // scatter through LDS; a full chunk none of whose entries moves keeps its registers (the candidates all
@@ -325,16 +334,17 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : FNV_SORTED_WAVES_PER_SIMD) void
 #pragma unroll
             for (int r = 0; r < R; r++) {
               moved[r] = false;
-              if (r * WAVE < n_new) {
+              if (r == 0 || r * WAVE < n_new) {
                 const int e = r * WAVE + lane;
                 const int np = e + c - (int)le[r];
+                const int live = n - r * WAVE;  // entries of this chunk (wave-uniform)
+                const unsigned long long vmask = live >= WAVE ? ~0ull : live <= 0 ? 0ull : (1ull << live) - 1ull;
                 const bool valid = e < n;
-                moved[r] = (r + 1) * WAVE > n || __ballot(valid && (int)le[r] != c) != 0ull;
+                moved[r] = live < WAVE || (__ballot((int)le[r] != c) & vmask) != 0ull;
                 if (moved[r]) {
                   const bool keep = valid && np < B;
                   beam[keep ? np : -1] = pack(fnv_stl::Entry{kr[r], ir[r]});
                   if (valid && !keep) {
-                    out_eq = true;
                     out_key = fminf(out_key, kr[r]);
                   }
                 }
@@ -344,7 +354,6 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : FNV_SORTED_WAVES_PER_SIMD) void
               const bool keep = pass && fpos < B;
               beam[keep ? fpos : -1] = pack(fnv_stl::Entry{d, cand_id});
               if (pass && !keep) {
-                out_eq = true;
                 out_key = fminf(out_key, d);
               }
             }
@@ -382,10 +391,12 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : FNV_SORTED_WAVES_PER_SIMD) void
                 const bool b = key <= readlane_f(d, i);
                 le += b ? 1 : 0;
                 const int cnt = __popcll(__ballot(b));
-                cntv = lane == i ? cnt : cntv;
+                cntv = writelane_i(cntv, cnt, i);
               }
               bpos += cntv;
-              if ((r + 1) * WAVE <= n && __ballot(valid && le != c) == 0ull) {
+              const int live = n - r * WAVE;
+              const unsigned long long vmask = live >= WAVE ? ~0ull : (1ull << live) - 1ull;
+              if ((r + 1) * WAVE <= n && (__ballot(le != c) & vmask) == 0ull) {
                 bpos += r * WAVE;  // the chunks below: every entry is <= every candidate
                 break;
               }
@@ -393,7 +404,6 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : FNV_SORTED_WAVES_PER_SIMD) void
               const bool keep = valid && np < B;
               beam[keep ? np : -1] = raw;
               if (valid && !keep) {
-                out_eq = true;
                 out_key = fminf(out_key, key);
               }
               if ((cur >> 6) == r && cur < n) shift_cur = c - __builtin_amdgcn_readlane(le, cur & (WAVE - 1));
@@ -403,7 +413,6 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : FNV_SORTED_WAVES_PER_SIMD) void
               const bool keep = pass && fpos < B;
               beam[keep ? fpos : -1] = pack(fnv_stl::Entry{d, cand_id});
               if (pass && !keep) {
-                out_eq = true;
                 out_key = fminf(out_key, d);
               }
             }
@@ -411,7 +420,7 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : FNV_SORTED_WAVES_PER_SIMD) void
             // first unexpanded entry: the old one where it went (gone if pushed out), or the closest candidate
             int cur_new = cur < n ? cur + shift_cur : NO_ENTRY;
             if (cur_new >= B) cur_new = NO_ENTRY;
-            const unsigned long long firstc = __ballot(pass && rank == 0u);  // exactly one candidate lane
+            const unsigned long long firstc = __ballot(rank == 0u) & pm;  // exactly one candidate lane
             const int fmin = __builtin_amdgcn_readlane(fpos, __ffsll((long long)firstc) - 1);
             if (fmin < B) cur_new = min(cur_new, fmin);
             cur = cur_new;
@@ -419,7 +428,7 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : FNV_SORTED_WAVES_PER_SIMD) void
             max_dist = rfl(unpack(beam[n - 1]).key);  // Index.h:702
           }
           // (a) an element left outside has the key of the new farthest member
-          if (__ballot(out_eq && out_key == max_dist) != 0ull) {
+          if (__ballot(out_key == max_dist) != 0ull) {  // (out_key is +inf in lanes that left nothing outside; max_dist is finite)
             amb = max_dist;
             if (pend > -INF) pend_cut = true;  // (b) likewise: which of the two is inside depends on the order
           }
@@ -428,7 +437,12 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : FNV_SORTED_WAVES_PER_SIMD) void
         }
         PH_MARK(6);
         wave_sync();  // stage_ids / stage_d are rewritten by the next row chunk
-      }
+        return true;
+      };
+
+      if (row_chunk(0, row0))
+        for (int m0 = WAVE; m0 < M; m0 += WAVE)
+          if (!row_chunk(m0, m0 + lane < M ? links[(uint64_t)(uint32_t)node * (uint32_t)M + m0 + lane] : EMPTY_ID)) break;
     }
 
     ColdArgs c = cold_args();

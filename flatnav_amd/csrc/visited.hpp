@@ -61,6 +61,26 @@ __device__ __forceinline__ void tag16_slot(const VisGeom& g, uint32_t h, uint32_
 // around the CAS itself -- the scalar unit that manipulates EXEC is shared by every wave of the CU.
 // bitmap / ovf_glist are this slot's HBM spill areas; they are only touched on the rare both-buckets-full path,
 // where the list capacity is re-read from the kernel arguments (cold_args).
+//
+// Round 3 (instruction diet: the hop of 128-byte rows is bound by instruction issue, and this probe was ~130 of its
+// ~560 instructions): a bucket fills in a fixed order -- low half of word 0, high half, low half of word 1, high half
+// (an insertion takes the lowest empty half of the first word that has one, and nothing is ever removed) -- so
+//   * "is the tag in one of the two buckets"  = some 16-bit half of {B1 ^ t1, B2 ^ t2} is zero: three packed 16-bit
+//     minima over the four words, one more across the two halves (was: eight exact has-zero-halfword tests);
+//   * "how full is a bucket" = position of its highest non-zero half, read off the leading zeros of the 64-bit word
+//     (was: four has-zero tests and four popcounts);
+//   * the slot to fill is that count: word = fill >> 1, half = fill & 1.
+typedef unsigned short fnv_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+  const fnv_u16x2 m = __builtin_elementwise_min(__builtin_bit_cast(fnv_u16x2, a), __builtin_bit_cast(fnv_u16x2, b));
+  return __builtin_bit_cast(uint32_t, m);
+}
+// halves in use (0..4) of a bucket that fills from the low half of .x to the high half of .y
+__device__ __forceinline__ uint32_t bucket_fill(const uint2& B) {
+  const uint32_t top = B.y ? B.y : B.x;                  // the word that holds the highest used half
+  return (B.y ? 2u : 0u) + (top ? 1u : 0u) + ((top >> 16) ? 1u : 0u);
+}
+
 __device__ __forceinline__ bool visited_insert_tag16(uint32_t* tab, const VisGeom& g, bool act, uint32_t id,
                                                      uint32_t* bitmap, uint32_t* ovf_list, uint32_t* ovf_glist,
                                                      bool& used_bitmap) {
@@ -72,32 +92,28 @@ __device__ __forceinline__ bool visited_insert_tag16(uint32_t* tab, const VisGeo
   while (__ballot(pending != 0u) != 0ull) {
     const uint2 B1 = *reinterpret_cast<const uint2*>(tab + 2 * b1);
     const uint2 B2 = *reinterpret_cast<const uint2*>(tab + 2 * b2);
-    // zero16(w): bit 15 / 31 set iff the low / high half of w is zero (exact "has-zero-halfword" test)
-#define FNV_ZERO16(w) ((~(((w) & 0x7FFF7FFFu) + 0x7FFF7FFFu) & ~(w)) & 0x80008000u)
-    const uint32_t hit = FNV_ZERO16(B1.x ^ t1x) | FNV_ZERO16(B1.y ^ t1x) | FNV_ZERO16(B2.x ^ t2x) | FNV_ZERO16(B2.y ^ t2x);
-    const uint32_t z1x = FNV_ZERO16(B1.x), z1y = FNV_ZERO16(B1.y), z2x = FNV_ZERO16(B2.x), z2y = FNV_ZERO16(B2.y);
-#undef FNV_ZERO16
-    const int e1 = __popc(z1x) + __popc(z1y), e2 = __popc(z2x) + __popc(z2y);
-    const uint32_t found = hit != 0u ? 1u : 0u;
-    const uint32_t full = (e1 | e2) == 0 ? 1u : 0u;
-    const bool first = e1 >= e2;  // insert into the emptier bucket
-    const uint32_t zx = first ? z1x : z2x;
+    // some half of the four xor-ed words is zero <=> the tag is there (tags are never zero, so an empty half is no hit)
+    const uint32_t m = pk_min_u16(pk_min_u16(B1.x ^ t1x, B1.y ^ t1x), pk_min_u16(B2.x ^ t2x, B2.y ^ t2x));
+    const uint32_t found = min(m & 0xFFFFu, m >> 16) == 0u ? 1u : 0u;
+    const uint32_t f1 = bucket_fill(B1), f2 = bucket_fill(B2);
+    const uint32_t full = min(f1, f2) == 4u ? 1u : 0u;
+    const bool first = f1 <= f2;  // insert into the emptier bucket
+    const uint32_t f = first ? f1 : f2;
     const uint32_t Bx = first ? B1.x : B2.x, By = first ? B1.y : B2.y;
     const uint32_t tag = first ? t1 : t2;
-    const bool in_x = zx != 0u;
-    const uint32_t oldw = in_x ? Bx : By;
-    const uint32_t neww = oldw | ((oldw & 0xFFFFu) == 0u ? tag : tag << 16);
+    const uint32_t oldw = (f & 2u) ? By : Bx;
+    const uint32_t neww = oldw | (tag << ((f & 1u) * 16u));
     const uint32_t try_cas = pending & (found ^ 1u) & (full ^ 1u);
     uint32_t got = ~oldw;
-    if (try_cas) got = atomicCAS(tab + 2 * (first ? b1 : b2) + (in_x ? 0 : 1), oldw, neww);
+    if (try_cas) got = atomicCAS(tab + 2 * (first ? b1 : b2) + (f >> 1), oldw, neww);
     const uint32_t won = try_cas & (got == oldw ? 1u : 0u);
     isnew |= won;
     const uint32_t to_bitmap = pending & (found ^ 1u) & full;  // both buckets full: the HBM bitmap decides (rare)
     if (__ballot(to_bitmap != 0u) != 0ull) {
+      used_bitmap = true;  // wave-uniform: set for every lane as soon as any lane's id goes to the bitmap
       if (to_bitmap) {
         const uint32_t bit = 1u << (id & 31);
         const uint32_t old = atomicOr(&bitmap[id >> 5], bit);
-        used_bitmap = true;
         if (!(old & bit)) {
           const uint32_t pos = atomicAdd(&ovf_list[0], 1u);
           // the first OVF_LIST ids are remembered so that a lightly used bitmap is cleared word by word; past
@@ -150,10 +166,10 @@ __device__ __forceinline__ bool visited_insert_tagw(unsigned long long* tab, con
     isnew |= won;
     const uint32_t to_bitmap = pending & (found ^ 1u) & full;
     if (__ballot(to_bitmap != 0u) != 0ull) {
+      used_bitmap = true;  // wave-uniform: set for every lane as soon as any lane's id goes to the bitmap
       if (to_bitmap) {
         const uint32_t bit = 1u << (id & 31);
         const uint32_t old = atomicOr(&bitmap[id >> 5], bit);
-        used_bitmap = true;
         if (!(old & bit)) {
           const uint32_t pos = atomicAdd(&ovf_list[0], 1u);
           if (pos < OVF_LIST) ovf_list[1 + pos] = id;

@@ -279,7 +279,8 @@ class DeviceIndex:
         timestamps (ns, steady clock) of the most recent host-buffer search."""
         r = (C.c_uint64 * 4)()
         check(lib().fnv_last_launch_info(self._h, r))
-        names = ["two_heaps", "merged_beam", "merged_beam_tail50", "merged_beam_tail75", "merged_beam_tail100"]
+        names = ["two_heaps", "merged_beam", "merged_beam_tail50", "merged_beam_tail75", "merged_beam_tail100",
+                 "merged_beam_tail25"]
         return {"variant": names[int(r[0])], "variant_id": int(r[0]), "exploratory": bool(r[1]),
                 "enqueued_ns": int(r[2]), "completed_ns": int(r[3])}
 

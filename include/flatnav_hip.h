@@ -170,12 +170,13 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *   "sorted_tail_exact_pct"  the last p % of one round of queries (one round = as many queries as stay resident)
  *                     of a merged-beam launch go straight to the exact search: a query that is searched twice
  *                     finishes late, and in the last round that lengthens the whole launch.  -1 (default) = one more
- *                     variant for the adaptive choice to measure (it tries 0, 50, 75 and 100); >= 0 = fixed
+ *                     variant for the adaptive choice to measure (it tries 0, 25, 50, 75 and 100); >= 0 = fixed
  *   "beam_registers"  != 0 (default): beams of at most 256 entries keep the sorted array in registers (the merge's
  *                     permutation goes through LDS); 0 = the array always lives in LDS, as it does for wider beams
- *   "sorted_variant"  -1 (default) = the adaptive choice above; 0..4 = pin what a merged-beam-capable launch runs:
- *                     0 two-heap kernel, 1 merged-beam kernel, 2 / 3 / 4 merged-beam kernel with the last 50 / 75 / 100 %
- *                     of a round straight to the exact search (launches of one round or less run 1 instead)
+ *   "sorted_variant"  -1 (default) = the adaptive choice above; 0..5 = pin what a merged-beam-capable launch runs:
+ *                     0 two-heap kernel, 1 merged-beam kernel, 2 / 3 / 4 / 5 merged-beam kernel with the last 50 / 75 /
+ *                     100 / 25 % of a round straight to the exact search (launches of one round or less run 1 instead)
+ *   "tune_layout"     1 (default): fnv_tune also measures the LDS layout (see fnv_tune); 0 = kernel variants only
  *   "sorted_beam_min" smallest beam width the merged-beam kernel is used for (default 1)
  *   "sorted_cand_lds" where the exact re-run of the merged-beam kernel keeps its candidates heap: 2 (default) = in LDS
  *                     when that costs neither resident queries nor visited-table slots, or -- beams of at most 128
@@ -248,12 +249,16 @@ int fnv_last_replayed_queries(fnv_index_t index, uint64_t out[5]);
  * went straight to the exact search (merged-beam kernel, see the "sorted_tail_exact_pct" option)}. */
 int fnv_last_launch_geometry(fnv_index_t index, uint64_t geom[8]);
 
-/* The adaptive kernel choice ("sorted_beam" = 2) measures its variants on the caller's launches: up to 15 launches per
+/* The adaptive kernel choice ("sorted_beam" = 2) measures its variants on the caller's launches: up to 18 launches per
  * (beam width, batch-size class) run a variant that is being sampled, not the final pick.  fnv_tune takes all those
  * samples in ONE call -- every variant, a cold launch plus three timed ones, on the given batch (host pointer, or
  * device pointer with queries_on_device != 0; results are discarded) -- so that the first launch afterwards with
  * the same K / ef_search and a batch of the same class (more than one round of resident queries or not) already runs
- * the final variant.  No-op when there is nothing to choose (pinned variant, non-adaptive mode, batches < 2048).
+ * the final variant.  Before that it measures the per-query LDS layout for this beam width: the rules' choice against
+ * its neighbours (candidates heap of the exact search in LDS or in HBM, visited table one size up / down -- what the
+ * "sorted_cand_lds" / "visited_slots" options would force; options the caller has set are respected) and keeps the
+ * fastest until an option changes.  Results never depend on any of this.
+ * No-op when there is nothing to choose (pinned variant, non-adaptive mode, batches < 2048).
  * There is no reference counterpart: the reference has one search routine (Index.h:606-707).
  * fnv_last_launch_info: info[4] = {variant of the most recent launch (numbering of "sorted_variant"), 1 if that
  * launch was an exploratory sample of the adaptive choice else 0, host steady-clock ns at which the most recent
