@@ -119,8 +119,9 @@ __device__ __forceinline__ void wave_sync() {
   asm volatile("" ::: "memory");
 }
 
+// Returns true when v ended up at the root (it climbed the whole ancestor chain, or the heap was empty).
 template <class H>
-__device__ __forceinline__ void coop_push(H& h, int n, fnv_stl::Entry v, int lane, PhaseTimer& ph, int phbase) {
+__device__ __forceinline__ bool coop_push(H& h, int n, fnv_stl::Entry v, int lane, PhaseTimer& ph, int phbase) {
   n = __builtin_amdgcn_readfirstlane(n);
   v.key = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.key)));
   v.val = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.val);
@@ -134,6 +135,33 @@ __device__ __forceinline__ void coop_push(H& h, int n, fnv_stl::Entry v, int lan
   h.set_if(lane <= t, (int)(m1 >> lane) - 1, lane < t ? anc : v);  // lanes < t: ancestor one level down; lane t: v
   wave_sync();
   ph.mark(phbase);
+  return t == depth;
+}
+
+// The same element pushed onto two independent heaps (the reference's candidates.emplace(-d, id) and
+// neighbors.emplace(d, id), Index.h:696-697): both ancestor chains are read before either vote, so the two pushes share
+// ONE LDS round trip.  Returns whether vb reached the root of hb.
+template <class HA, class HB>
+__device__ __forceinline__ bool coop_push2(HA& ha, int na, fnv_stl::Entry va, HB& hb, int nb, fnv_stl::Entry vb, int lane,
+                                           PhaseTimer& ph, int phbase) {
+  na = __builtin_amdgcn_readfirstlane(na);
+  nb = __builtin_amdgcn_readfirstlane(nb);
+  va.key = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(va.key)));
+  va.val = (uint32_t)__builtin_amdgcn_readfirstlane((int)va.val);
+  vb.key = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(vb.key)));
+  vb.val = (uint32_t)__builtin_amdgcn_readfirstlane((int)vb.val);
+  const uint32_t ma = (uint32_t)na + 1u, mb = (uint32_t)nb + 1u;
+  const int da = 31 - __clz((int)ma), db = 31 - __clz((int)mb);
+  const fnv_stl::Entry anca = ha.get(max((int)(ma >> (uint32_t)min(lane + 1, da)) - 1, 0));
+  const fnv_stl::Entry ancb = hb.get(max((int)(mb >> (uint32_t)min(lane + 1, db)) - 1, 0));
+  const unsigned long long runa = __ballot(lane < da && anca.key < va.key);
+  const unsigned long long runb = __ballot(lane < db && ancb.key < vb.key);
+  const int ta = __ffsll((long long)~runa) - 1, tb = __ffsll((long long)~runb) - 1;
+  ha.set_if(lane <= ta, (int)(ma >> lane) - 1, lane < ta ? anca : va);
+  hb.set_if(lane <= tb, (int)(mb >> lane) - 1, lane < tb ? ancb : vb);
+  wave_sync();
+  ph.mark(phbase);
+  return tb == db;
 }
 
 // One step of the root-to-leaf walk in 1-based numbering: m <- 2*m + mask[bit].  Two scalar instructions
@@ -145,14 +173,16 @@ __device__ __forceinline__ uint32_t walk_step(uint32_t m, unsigned long long mas
 
 // KEEP_TOP: also park the removed top in the vacated slot, as std::pop_heap does (only the result tail
 // needs that; the beam loop never looks at the slot again).
+// Returns the key of the new root (what priority_queue::top() reads next) -- from registers, not from memory;
+// meaningless when n <= 1.
 template <bool KEEP_TOP, class H>
-__device__ __forceinline__ void coop_pop(H& h, int n, int lane, PhaseTimer& ph, int phbase) {
+__device__ __forceinline__ float coop_pop(H& h, int n, int lane, PhaseTimer& ph, int phbase) {
   n = __builtin_amdgcn_readfirstlane(n);
-  if (n <= 1) return;  // std::pop_heap does nothing for a single element
+  if (n <= 1) return 0.f;  // std::pop_heap does nothing for a single element
   if (n > 8192) {      // more two-child nodes than 64 lanes x 64 mask bits: plain sequential form
     if (lane == 0) fnv_stl::heap_pop(h, n);
     wave_sync();
-    return;
+    return h.get(0).key;
   }
   const int len = n - 1;
   const fnv_stl::Entry v_raw = h.get(len);  // same address in all lanes (broadcast); used in phase 3
@@ -225,10 +255,12 @@ __device__ __forceinline__ void coop_pop(H& h, int n, int lane, PhaseTimer& ph, 
   }
   const unsigned long long fail = ~__ballot(back) & ((1ull << L) - 1ull);  // L <= 31
   const int jf = fail ? 63 - __clzll((long long)fail) : -1;  // deepest level whose move survives
-  h.set_if(lane <= jf + 1, my_p, lane <= jf ? val : v);
+  const fnv_stl::Entry put = lane <= jf ? val : v;
+  h.set_if(lane <= jf + 1, my_p, put);
   if (KEEP_TOP && lane == 0) h.set(len, top);  // std::pop_heap parks the old top in the vacated slot
   wave_sync();
   ph.mark(phbase + 2);
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(put.key)));  // lane 0 writes the root
 }
 
 }  // namespace fnv_dev

@@ -321,8 +321,11 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, int qi, uint32_t 
             const float di = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cd[pu]), i));
             const uint32_t idi = (uint32_t)__builtin_amdgcn_readlane((int)cid[pu], i);
             if (nbr_n < B || di < max_dist) {  // Index.h:693
+              // max_dist == neighbors.top().first throughout (Index.h:702), so the new top is known without reading
+              // the heap back: a push changes it only if the new element climbs to the root, a pop reports it
+              bool at_root;
               if (cand_n < cand_slots) {
-                coop_push(cand, cand_n, fnv_stl::Entry{-di, idi}, lane, ph, 11);
+                at_root = coop_push2(cand, cand_n, fnv_stl::Entry{-di, idi}, nbr, nbr_n, fnv_stl::Entry{di, idi}, lane, ph, 11);
               } else {
                 const int spill_entries = (int)cold_args()->spill_entries;
                 if (cand_n >= cand_slots + spill_entries) {
@@ -334,12 +337,12 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, int qi, uint32_t 
                 __threadfence_block();
                 coop_push(cand_big, cand_n, fnv_stl::Entry{-di, idi}, lane, ph, 11);
                 __threadfence_block();
+                at_root = coop_push(nbr, nbr_n, fnv_stl::Entry{di, idi}, lane, ph, 12);
               }
-              coop_push(nbr, nbr_n, fnv_stl::Entry{di, idi}, lane, ph, 12);
-              if (nbr_n + 1 > B) coop_pop<false>(nbr, nbr_n + 1, lane, ph, 13);
+              if (at_root) max_dist = di;
+              if (nbr_n + 1 > B) max_dist = coop_pop<false>(nbr, nbr_n + 1, lane, ph, 13);
               cand_n++;
               if (nbr_n < B) nbr_n++;
-              max_dist = rfl(nbr.get(0).key);
             }
           }
           if (err) break;
