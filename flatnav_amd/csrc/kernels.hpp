@@ -195,9 +195,11 @@ struct ExactCtx {
   uint32_t* ovf_list;
 };
 
+// `stop` (null: never) = a word another wavefront sets once the same query has been answered (shadow mode, search_params.h):
+// polled once per hop; the search then gives up -- no results written, per-slot state left clean.
 template <typename T, int METRIC, int G, int CU, bool FULL>
 __device__ __forceinline__ void exact_query(const ExactCtx& x, int qi, uint32_t entry, float best_d, int lane,
-                                            PhaseTimer& ph) {
+                                            PhaseTimer& ph, const uint32_t* stop = nullptr) {
   constexpr int PU = passes<G, CU>();
   const uint8_t* const vectors = x.vectors;
   const uint32_t* const links = x.links;
@@ -233,6 +235,7 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, int qi, uint32_t 
   }
   // (ovf is wave-uniform: the visited inserts set it for every lane)
   int err = ST_OK;
+  bool aborted = false;
   uint32_t n_dist = 0, n_hops = 0;
   if (cand_slots == 0) __threadfence_block();
   __syncthreads();
@@ -248,6 +251,8 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, int qi, uint32_t 
     // issue the link-row load now; the cooperative pop below hides most of its HBM latency
     uint32_t row_id = EMPTY_ID;
     if (lane < M) row_id = links[(uint64_t)(uint32_t)node * (uint32_t)M + lane];
+    uint32_t stop_now = 0u;  // (read past this CU's L1: another CU writes it)
+    if (stop) stop_now = __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cand_n <= cand_slots) {
       coop_pop<false>(cand, cand_n, lane, ph, 8);
     } else {  // part of the heap lives in the HBM spill area
@@ -259,6 +264,10 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, int qi, uint32_t 
     cand_n--;
     n_hops++;
     PH_MARK(2);
+    if (stop && rfl((int)stop_now) != 0) {  // the merged-beam pass has answered this query
+      aborted = true;
+      break;
+    }
 
     for (int m0 = 0; m0 < M; m0 += WAVE) {
       const bool act = m0 + lane < M;
@@ -357,6 +366,11 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, int qi, uint32_t 
   }
   PH_MARK(2);
 
+  if (aborted) {  // nothing to report; hand the slot's HBM bitmap back clean
+    if (ovf) clear_spill_bitmap(bitmap, ovf_list, ovf_glist, tagged, lane);
+    __syncthreads();
+    return;
+  }
   // ---- results (Index.h:393-408): drain, std::sort by distance, truncate to K --------------
   __syncthreads();
   const int K = cold_args()->K;

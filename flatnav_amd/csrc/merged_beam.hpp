@@ -117,8 +117,12 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : FNV_SORTED_WAVES_PER_SIMD) void
   const float INF = std::numeric_limits<float>::infinity();
 
   while (true) {
-    const int qi = next_query(lane);
-    if (qi < 0) break;
+    const int item = next_query(lane);
+    if (item < 0) break;
+    // shadow mode (search_params.h): items >= shadow_base are exact searches of query item - shadow_base
+    const uint32_t shadow_base = cold_args()->shadow_base;
+    const bool shadow = shadow_base != 0u && (uint32_t)item >= shadow_base;
+    const int qi = shadow ? item - (int)shadow_base : item;
     PH_DECL
     // Per-query constants are re-read from the kernel arguments at the top of every query (a dozen scalar loads) and
     // again by the exact re-run below: nothing but the loop itself is then live across the two code paths, so the
@@ -172,7 +176,8 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : FNV_SORTED_WAVES_PER_SIMD) void
     if (vg.w == 16) visited_insert_tag16(vis, vg, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
     else visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), vg, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
     int tie = best_d != best_d ? 4 : 0;
-    if ((uint32_t)qi + ca->tail_exact >= ca->nq) tie = 5;  // last round of the launch: straight to the exact search
+    if ((uint32_t)item + ca->tail_exact >= ca->nq) tie = 5;  // last round of the launch: straight to the exact search
+    if (shadow) tie = 5;
     float amb = INF;    // (a) pending: key at which the reference's eviction choice is unknown
     float pend = -INF;  // (b) pending: largest key at which two unexpanded members tied
     bool pend_cut = false;  // ... and, while it is pending, equal keys met where the beam is cut (see the header)
@@ -480,6 +485,11 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : FNV_SORTED_WAVES_PER_SIMD) void
         atomicAdd(rc + tie, 1u);
       }
       if (ovf) clear_spill_bitmap(bitmap, ovf_list, ovf_glist, true, lane);
+      if (shadow_base != 0u && !shadow) {  // its shadow has been searching this query exactly since the launch began
+        PH_FLUSH;
+        __syncthreads();
+        continue;
+      }
       reset_visited(vis, ovf_list, true, lane);
       __syncthreads();
       ColdArgs xa = cold_args();
@@ -499,7 +509,7 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : FNV_SORTED_WAVES_PER_SIMD) void
       x.vis = reinterpret_cast<uint32_t*>(smem + xa->off_vis);
       x.stage_ids = reinterpret_cast<uint32_t*>(smem + xa->off_stage_ids);
       x.ovf_list = reinterpret_cast<uint32_t*>(smem + xa->off_ovf);
-      exact_query<T, METRIC, G, CU, FULL>(x, qi, entry, best_d, lane, ph);
+      exact_query<T, METRIC, G, CU, FULL>(x, qi, entry, best_d, lane, ph, shadow ? xa->done_flags + qi : nullptr);
       PH_FLUSH;
       continue;
     } else {
@@ -529,6 +539,8 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : FNV_SORTED_WAVES_PER_SIMD) void
         if (c->out_count) c->out_count[qi] = cnt;
         if (c->out_ndist) c->out_ndist[qi] = n_dist;
         if (c->out_nhops) c->out_nhops[qi] = n_hops;
+        // answered: the shadow may stop (it writes the same bytes if it gets there first, so no ordering is needed)
+        if (shadow_base != 0u) __hip_atomic_store(c->done_flags + qi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     if (ovf) clear_spill_bitmap(bitmap, ovf_list, ovf_glist, true, lane);

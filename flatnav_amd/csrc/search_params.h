@@ -74,6 +74,12 @@ struct SearchParams {
   uint32_t off_stage_d;     // LDS: [WAVE + 1] distances of a link row's unvisited neighbours (merged-beam kernel; = off_nbr:
                             // the permutation buffer is idle while they are staged)
   uint32_t tail_exact;     // merged-beam kernel: the last tail_exact queries of the launch skip the sorted pass
+  // Shadow mode (small launches: every query and its shadow are resident from the start): work items >= shadow_base are
+  // exact (two-heap) searches of query item - shadow_base, started TOGETHER with the merged-beam search of the same query;
+  // the merged-beam pass never re-runs a query (its shadow is already under way) and tells the shadow to stop when it
+  // finishes without a tie.  0 = off.  done_flags: [shadow_base] words, zero at launch.
+  uint32_t shadow_base;
+  uint32_t* done_flags;
 };
 
 // Broadcast of lane 0's value into a scalar register ("this value is wave-uniform").

@@ -176,6 +176,11 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *   "sorted_variant"  -1 (default) = the adaptive choice above; 0..5 = pin what a merged-beam-capable launch runs:
  *                     0 two-heap kernel, 1 merged-beam kernel, 2 / 3 / 4 / 5 merged-beam kernel with the last 50 / 75 /
  *                     100 / 25 % of a round straight to the exact search (launches of one round or less run 1 instead)
+ *   "shadow_exact"    1 (default): a launch that fills at most a quarter of the resident query slots (a single query, a
+ *                     batch of 64 ...) starts, next to the merged-beam search of every query, an exact two-heap search of
+ *                     the same query on another slot; a query in which equal distances meet at a decision is then
+ *                     answered after one exact-search latency from the start of the launch instead of a merged-beam pass
+ *                     plus a re-run, the shadow of a query that needs none stops at its next hop.  0 = off.  Same bytes.
  *   "tune_layout"     1 (default): fnv_tune also measures the LDS layout (see fnv_tune); 0 = kernel variants only
  *   "sorted_beam_min" smallest beam width the merged-beam kernel is used for (default 1)
  *   "sorted_cand_lds" where the exact re-run of the merged-beam kernel keeps its candidates heap: 2 (default) = in LDS
@@ -260,8 +265,9 @@ int fnv_last_launch_geometry(fnv_index_t index, uint64_t geom[8]);
  * fastest until an option changes.  Results never depend on any of this.
  * No-op when there is nothing to choose (pinned variant, non-adaptive mode, batches < 2048).
  * There is no reference counterpart: the reference has one search routine (Index.h:606-707).
- * fnv_last_launch_info: info[4] = {variant of the most recent launch (numbering of "sorted_variant"), 1 if that
- * launch was an exploratory sample of the adaptive choice else 0, host steady-clock ns at which the most recent
+ * fnv_last_launch_info: info[4] = {variant of the most recent launch (numbering of "sorted_variant"), bit 0: that
+ * launch was an exploratory sample of the adaptive choice, bit 1: it ran in shadow mode ("shadow_exact"), host
+ * steady-clock ns at which the most recent
  * host-buffer search was enqueued, ... at which it completed (both 0 before the first one)}. */
 int fnv_tune(fnv_index_t index, const void* queries, uint64_t nq, int queries_on_device, int K, int ef_search,
              int num_initializations);

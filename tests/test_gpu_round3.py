@@ -165,6 +165,55 @@ def test_tune_measures_the_lds_layout_and_never_changes_results(oracle_mod, hipm
     assert dev.launch_geometry()["visited_slots"] == 2048
 
 
+@pytest.mark.parametrize("case", ["u8_every_query_ties", "f32_integer_valued", "f32_real"])
+def test_small_launches_run_exact_shadows(oracle_mod, hipmod, case):
+    # "shadow_exact": a launch that fills at most a quarter of the slots runs, next to the merged-beam search of every
+    # query, an exact search of the same query -- answers stay the oracle's, tie or no tie, shadow or no shadow
+    rng = np.random.default_rng(11)
+    if case == "u8_every_query_ties":
+        X = rng.integers(0, 4, (6000, 16)).astype(np.uint8)
+        Q = rng.integers(0, 4, (700, 16)).astype(np.uint8)
+        dt, metric = "uint8", "l2"
+    elif case == "f32_integer_valued":
+        X, Q = ds.sift_like(8000, 700)
+        dt, metric = "float32", "l2"
+    else:
+        X, Q = ds.lowrank_normalized(8000, 700, dim=100, rank=24, seed=100)
+        dt, metric = "float32", "angular"
+    ix = oracle_mod.OracleIndex.create(metric, X.shape[1], len(X), 16, dt)
+    ix.add(X, 48, threads=8)
+    dev = _upload(hipmod, ix)
+    exact_ids = case != "f32_real"
+    for ef, K in ((40, 10), (150, 25)):
+        want = ix.search(Q, K, ef, stats=True)
+        for nq in (1, 7, 64, 700):
+            for mode in (1, 0):
+                dev.set_option("shadow_exact", mode)
+                got = dev.search(Q[:nq], K, ef, stats=True)
+                info = dev.launch_info()
+                assert info["shadow"] == bool(mode), (nq, mode, info, dev.launch_geometry())
+                if exact_ids:
+                    assert np.array_equal(want[1][:nq], got[1]) and np.array_equal(want[0][:nq].view(np.uint32), got[0].view(np.uint32))
+                    assert all(np.array_equal(want[2][k][:nq], got[2][k]) for k in ("count", "n_dist", "n_hops")), (case, nq, mode)
+                else:
+                    same = (want[1][:nq] == got[1]).all(axis=1)
+                    assert same.mean() >= 0.99 and np.allclose(want[0][:nq][same], got[0][same], rtol=1e-5, atol=1e-6)
+        if case == "u8_every_query_ties":
+            dev.set_option("shadow_exact", 1)
+            dev.search(Q[:64], K, ef)
+            assert dev.replayed_queries()["total"] > 30  # the merged-beam pass gave most of them up: their shadows answered
+    # repeated small launches leave the per-slot state clean (stopped shadows hand their HBM bitmap back zeroed)
+    dev.set_option("shadow_exact", 1)
+    dev.set_option("visited_slots", 256)  # force ids into the HBM bitmap
+    first = dev.search(Q[:64], 10, 150, stats=True)
+    for _ in range(5):
+        again = dev.search(Q[:64], 10, 150, stats=True)
+        assert np.array_equal(first[1], again[1]) and np.array_equal(first[0], again[0])
+        assert np.array_equal(first[2]["n_dist"], again[2]["n_dist"])
+    big = dev.search(Q, 10, 150, stats=True)  # and a launch without shadows afterwards sees clean bitmaps
+    assert np.array_equal(big[1][:64], first[1]) and np.array_equal(big[2]["n_dist"][:64], first[2]["n_dist"])
+
+
 def test_views_count_on_their_source(oracle_mod, hipmod):
     X, Q = ds.sift_like(8000, 300)
     ix = oracle_mod.OracleIndex.create("l2", 128, 8000, 16)
