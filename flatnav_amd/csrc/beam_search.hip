@@ -1446,7 +1446,7 @@ int fnv_gather_ceiling(fnv_index_t ix, int waves_per_cu, double* gbps_out) {
                                               gather_ceiling_kernel<16, 4>, gather_ceiling_kernel<32, 4>, gather_ceiling_kernel<64, 4>,
                                               gather_ceiling_kernel<64, 3>};
   const int G = kCfgs[cfg].G, CU = kCfgs[cfg].CU;
-  const int PU = (G == 64 && CU == 3) ? 4 : PU_DEFAULT;
+  const int PU = passes_of(G, CU);
   const int wpc = waves_per_cu > 0 ? std::min(waves_per_cu, 32) : 16;
   const uint32_t blocks = (uint32_t)(ix->num_cus * wpc);
   const double rows_per_iter = (double)blocks * (WAVE / G) * PU;  // rows one iteration of the whole grid reads

@@ -447,7 +447,7 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, int qi, uint32_t 
 }
 
 template <typename T, int METRIC, int G, int CU, bool FULL>
-__global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void beam_search_kernel(const SearchParams p) {
+__global__ __launch_bounds__(WAVE, waves_per_simd<G>(FNV_MIN_WAVES_PER_SIMD)) void beam_search_kernel(const SearchParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
   // hot parameters (scalar registers for the whole launch); everything else is re-read where it is used

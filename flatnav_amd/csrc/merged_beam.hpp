@@ -109,7 +109,7 @@ __device__ __forceinline__ float lane_of(const float (&a)[R], int r, int l) {
 }
 
 template <typename T, int METRIC, int G, int CU, bool FULL, int R>
-__global__ __launch_bounds__(WAVE, CU == 1 ? 5 : FNV_SORTED_WAVES_PER_SIMD) void beam_search_merged_kernel(const SearchParams p) {
+__global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WAVES_PER_SIMD)) void beam_search_merged_kernel(const SearchParams p) {
   // (128-byte rows: 97 registers as compiled for four waves per SIMD -- one over the budget of five, which they fit)
   constexpr int PU = passes<G, CU>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

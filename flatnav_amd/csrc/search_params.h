@@ -19,9 +19,29 @@ constexpr int WAVE = 64;
 constexpr int PU_DEFAULT = FNV_PU;  // vector "passes" whose loads are issued back to back before any use
 // Rows of a whole number of 192-chunk spans (768-d, 1536-d float32 ...) run with G = 64, CU = 3 -- every lane loads
 // exactly its three chunks, no clamping -- and four vectors in flight: the same 12 loads per lane as PU_DEFAULT x 4.
+// Round 3 experiment (gpurun_out/r3_run11): rows of 3 KB and more (G = 64) keep so few queries resident (LDS: 8-10 per CU at
+// 768-d) that half the register file is idle; compiling those instantiations for two waves per SIMD with 6 or 8 passes
+// (18-24 loads per lane in flight, what a pure gather of 3 KB rows needs to reach its ceiling) gained nothing -- 85.7 k ->
+// 86.0 k / 84.6 k queries/s at 3M x 768, ef=800, and cost a resident query at ef=200: that kernel's hop is paced by the
+// on-chip work between two gathers (a 13-chunk LDS merge, the visited probe), not by bytes in flight.  Defaults unchanged;
+// the knobs stay for the next look.  Which vectors are in flight together never changes a distance.
+#ifndef FNV_PU_64_3
+#define FNV_PU_64_3 4
+#endif
+#ifndef FNV_PU_64_4
+#define FNV_PU_64_4 3
+#endif
+#ifndef FNV_WAVES_G64
+#define FNV_WAVES_G64 4
+#endif
 template <int G, int CU>
 constexpr int passes() {
-  return (G == 64 && CU == 3) ? 4 : PU_DEFAULT;
+  return (G == 64 && CU == 3) ? FNV_PU_64_3 : (G == 64 && CU == 4) ? FNV_PU_64_4 : PU_DEFAULT;
+}
+constexpr int passes_of(int G, int CU) { return (G == 64 && CU == 3) ? FNV_PU_64_3 : (G == 64 && CU == 4) ? FNV_PU_64_4 : PU_DEFAULT; }
+template <int G>
+constexpr int waves_per_simd(int deflt) {
+  return G == 64 ? FNV_WAVES_G64 : deflt;
 }
 #ifndef FNV_MIN_WAVES_PER_SIMD
 #define FNV_MIN_WAVES_PER_SIMD 4  // __launch_bounds__ 2nd argument: register budget 512/4 = 128 per lane
