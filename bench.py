@@ -480,13 +480,13 @@ def run_config(ctx, args, config, main_line):
     #      occupancy) overlaps the start of the next.  This is the rate a server that always has the next batch ready
     #      sustains; the contract line above is one batch at a time on one stream.
     pipelined = None
-    if main_line and world == 1 and not args.no_secondary:
+    if world == 1 and not args.no_secondary:
         view = dev.view()
         view.tune(int(dq[0].data_ptr()), K, EF, 100, nq=NQ)
         s2 = torch.cuda.Stream()
         outs2 = (torch.empty((NQ, K), dtype=torch.float32, device=dev_t), torch.empty((NQ, K), dtype=torch.int32, device=dev_t))
         lanes = [(dev, stream, d_dist, d_lab), (view, s2, outs2[0], outs2[1])]
-        psteps = max(args.steps, 20)
+        psteps = max(args.steps, 20) if main_line else max(args.steps, 6)
 
         def pipe_run(n):
             for i in range(n):
@@ -597,8 +597,7 @@ def run_config(ctx, args, config, main_line):
             "pipelined": pipelined,
         }
         if not main_line:
-            for k in ("sustained", "pipelined"):
-                out.pop(k)
+            out.pop("sustained")
             out["ef_lines"] = out.pop("secondary")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(index, dev, Q_rank[0], K, EF, hw, DT, metric, seconds=8.0 if main_line else 5.0)

@@ -76,22 +76,28 @@ for dt in ("float32", "uint8"):
     })
     c, m = counters("sq_" + dt)
     sq[dt] = {"kernel": m, "per_launch": c}
-try:  # the wide-beam pass (config c4 at ef=400)
-    wb = json.load(open(os.path.join(O, "bench_c4_ef400.json")))
-    f, meta = counters("fetch_c4wide")
-    w, _ = counters("write_c4wide")
-    F, W = f["FETCH_SIZE"], w["WRITE_SIZE"]
-    alg = wb["roofline"]["achieved"] * 1e9 * wb["roofline"]["avg_kernel_ms"] / 1e3
-    traffic.append({"config": "c4", "dtype": "float32", "n": wb["config"].get("n"), "nq": 10000, "ef": 400, "kernel": meta,
-                    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --config c4 --no-cpu-baseline "
-                               "--no-secondary --sustain-seconds 0 --ef 400 --steps 3 --warmup 3",
-                    "FETCH_SIZE_KB_per_launch": F, "WRITE_SIZE_KB_per_launch": W,
-                    "hbm_bytes_per_launch_uncorrected": (F + W) * 1024, "hbm_bytes_per_launch_corrected": (2 * F + W) * 1024,
-                    "algorithmic_bytes_per_launch": alg,
-                    "note": "400-byte rows straddle four 128-byte lines (x1.28 of the algorithmic row bytes); the write side and the rest "
-                            "of the excess is the visited set's per-slot HBM bitmap (ids beyond the LDS table: read-modify-write of one line each)"})
-except (OSError, KeyError, SystemExit) as e:
-    print("no wide-beam pass:", e)
+for efw in (110, 200, 400):  # 100-d rows (config c4): 400-byte rows at a 512-byte stride since round 3
+    try:
+        wb = json.load(open(os.path.join(O, "bench_c4_ef%d.json" % efw)))
+        f, meta = counters("fetch_c4_ef%d" % efw)
+        w, _ = counters("write_c4_ef%d" % efw)
+        F, W = f["FETCH_SIZE"], w["WRITE_SIZE"]
+        r = wb["roofline"]
+        corrected = (2 * F + W) * 1024
+        traffic.append({"config": "c4", "dtype": "float32", "n": 1183514, "nq": 10000, "ef": efw, "kernel": meta,
+                        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --config c4 --no-cpu-baseline "
+                                   "--no-secondary --sustain-seconds 0 --ef %d --steps 3 --warmup 3" % efw,
+                        "FETCH_SIZE_KB_per_launch": F, "WRITE_SIZE_KB_per_launch": W,
+                        "hbm_bytes_per_launch_uncorrected": (F + W) * 1024, "hbm_bytes_per_launch_corrected": corrected,
+                        "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
+                        "line_bytes_per_launch": r["line_bytes_per_launch"],
+                        "traffic_over_algorithmic": corrected / r["algorithmic_bytes_per_launch"],
+                        "traffic_over_line_bytes": corrected / r["line_bytes_per_launch"],
+                        "row_bytes": r["row_bytes"], "row_stride_bytes": r["row_stride_bytes"],
+                        "note": "100-d float32 rows: 400 bytes of data in a 512-byte (four-line) stride; the write side is the visited "
+                                "set's per-slot HBM bitmap (ids beyond the LDS table: read-modify-write of one line each)"})
+    except (OSError, KeyError, SystemExit) as e:
+        print("no c4 pass at ef=%d:" % efw, e)
 json.dump([t for t in traffic if t["dtype"] == "float32"] + [t for t in traffic if t["dtype"] != "float32"],
           open(os.path.join(P, "%s_pmc_hbm_traffic.json" % tag), "w"), indent=1)
 json.dump({"ef": bench["config"]["ef_search"], "counters": sq}, open(os.path.join(P, "%s_sq_counters.json" % tag), "w"), indent=1)
