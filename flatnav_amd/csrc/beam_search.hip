@@ -1338,10 +1338,23 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(ix->stream));
   if (ix->geom[6] == MODE_HEAPS || ix->sorted_beam != 2 || ix->sorted_variant >= 0 || nq < 2048) return FNV_OK;  // nothing to choose
+  // Every timed launch starts from cold caches: the SAME queries visit the same nodes launch after launch, so the index
+  // rows and -- above all -- the words of the per-slot HBM visited bitmaps they touch would sit in the 256 MiB Infinity
+  // Cache by the second launch, which flatters exactly the layouts that spill most (small visited tables); a caller's
+  // consecutive batches are different queries.  (Measured: without this the layout choice for 100-d rows at ef=200
+  // flipped between boxes to a 4096-slot table that is 10 % slower under the bench protocol.)
+  struct Flush {
+    void* p = nullptr;
+    size_t bytes = 768u << 20;
+    ~Flush() { if (p) (void)hipFree(p); }
+  } flush;
+  if (hipMalloc(&flush.p, flush.bytes) != hipSuccess) flush.p = nullptr;  // (no room: tune warm, as before)
+  (void)hipGetLastError();
   // mean of `reps` timed launches of one variant, each on another rotation of the batch (after a cold launch), ms per query
   auto time_variant = [&](int v, int reps, float* out) -> int {
     float sum = 0.f;
     for (int rep = 0; rep <= reps; rep++) {
+      if (rep > 0 && flush.p) HIP_TRY(hipMemsetAsync(flush.p, rep, flush.bytes, ix->stream));
       const int r = launch(v, rep == 0 ? 0 : (uint64_t)(rep - 1) * nq / (uint64_t)reps);
       if (r) return r;
       HIP_TRY(hipStreamSynchronize(ix->stream));

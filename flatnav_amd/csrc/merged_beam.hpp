@@ -188,6 +188,7 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
       // ---- pick the closest unexpanded member; (b) its runner-up must not have the same key -------------------
       int node;
       float key_c;
+      uint32_t row0;  // the node's link row: requested as soon as the node is known (round 3), ahead of the tie bookkeeping
       if constexpr (R > 0) {
         int r1 = -1, l1 = 0, r2 = -1, l2 = 0;  // closest unexpanded member (chunk, lane) and its runner-up
 #pragma unroll
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
         }
         if (r1 < 0) break;  // every beam member expanded: what is left in the reference's queue is stale
         node = lane_of(ir, r1, l1);
+        row0 = lane < M ? links[(uint64_t)(uint32_t)node * (uint32_t)M + lane] : EMPTY_ID;
         key_c = lane_of(kr, r1, l1);
         if (r2 >= 0 && lane_of(kr, r2, l2) == key_c) pend = fmaxf(pend, key_c);
 #pragma unroll
@@ -217,6 +219,7 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
         const int c0 = cur;
         fnv_stl::Entry w = unpack(beam[min(c0 + lane, n - 1)]);
         node = __builtin_amdgcn_readlane((int)w.val, 0);
+        row0 = lane < M ? links[(uint64_t)(uint32_t)node * (uint32_t)M + lane] : EMPTY_ID;
         key_c = readlane_f(w.key, 0);
         int c2 = NO_ENTRY;
         for (int base = c0;;) {
@@ -247,7 +250,6 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
       }
       n_hops++;
       PH_MARK(2);
-      const uint32_t row0 = lane < M ? links[(uint64_t)(uint32_t)node * (uint32_t)M + lane] : EMPTY_ID;
       PH_MARK(3);
 
       // One 64-link chunk of the row: visited test-and-mark, gather + distances of the new ones, merge.  Returns false
