@@ -133,36 +133,54 @@ __device__ __forceinline__ bool visited_insert_tag16(uint32_t* tab, const VisGeo
 
 // The same scheme with 64-bit buckets of three 21-bit or two 32-bit tags, for id ranges whose remainder does not fit
 // 16 bits at an affordable bucket count (N > 2^24 at 4096 slots): tag width w needs nbits - k <= w - 2.
-// zero-field test, exact per field: Z(x) = ~(((x & Lo) + Lo) | x) & H  (H = field MSBs, Lo = the other field bits).
+// Round 3: rewritten on the two 32-bit halves of the bucket word (it was 64-bit has-zero-field arithmetic with a 64-bit
+// multiply to replicate the tag: ~150 instructions per link row; now ~70).  As in the 16-bit table a bucket fills from its
+// lowest field upwards and nothing is ever removed, so "how full" is the number of non-zero fields and the slot to fill is
+// that count; "is the tag there" is a three-way minimum of the xor-ed fields.
+//   w = 21: fields at bits 0-20, 21-41, 42-62 of {hi, lo};   w = 32: the fields ARE lo and hi.
 __device__ __forceinline__ bool visited_insert_tagw(unsigned long long* tab, const VisGeom& g, bool act, uint32_t id,
                                                     uint32_t* bitmap, uint32_t* ovf_list, uint32_t* ovf_glist,
                                                     bool& used_bitmap) {
   const uint32_t h1 = (id * 0x9E3779B1u) & g.nmask, h2 = (id * 0x85EBCA6Bu) & g.nmask;
   const uint32_t b1 = h1 >> g.rshift, b2 = h2 >> g.rshift;
-  const unsigned long long t1 = ((unsigned long long)(h1 & g.rmask) << 1) + 1ull;
-  const unsigned long long t2 = ((unsigned long long)(h2 & g.rmask) << 1) + 2ull;
-  // field replication multiplier, field MSBs, the other field bits: three 21-bit or two 32-bit fields
-  const unsigned long long R = g.w == 21 ? (1ull | (1ull << 21) | (1ull << 42)) : (1ull | (1ull << 32));
-  const unsigned long long H = R << (g.w - 1), Lo = R * ((1ull << (g.w - 1)) - 1ull);
-  const unsigned long long t1x = t1 * R, t2x = t2 * R;  // the tag in every field
+  const uint32_t t1 = ((h1 & g.rmask) << 1) + 1u, t2 = ((h2 & g.rmask) << 1) + 2u;  // never zero; < 2^w
+  const bool w21 = g.w == 21;  // wave-uniform
+  constexpr uint32_t M21 = 0x1FFFFFu;
+  uint2* tab2 = reinterpret_cast<uint2*>(tab);
   uint32_t pending = act ? 1u : 0u, isnew = 0u;
   while (__ballot(pending != 0u) != 0ull) {
-    const unsigned long long B1 = tab[b1], B2 = tab[b2];
-#define FNV_ZEROW(x) (~((((x) & Lo) + Lo) | (x)) & H)
-    const unsigned long long hit = FNV_ZEROW(B1 ^ t1x) | FNV_ZEROW(B2 ^ t2x);
-    const unsigned long long z1 = FNV_ZEROW(B1), z2 = FNV_ZEROW(B2);
-#undef FNV_ZEROW
-    const int e1 = __popcll(z1), e2 = __popcll(z2);
-    const uint32_t found = hit != 0ull ? 1u : 0u;
-    const uint32_t full = (e1 | e2) == 0 ? 1u : 0u;
-    const bool first = e1 >= e2;  // insert into the emptier bucket
-    const unsigned long long z = first ? z1 : z2, oldw = first ? B1 : B2, tag = first ? t1 : t2;
-    const int shift = z ? __ffsll((long long)z) - (int)g.w : 0;  // lowest empty field: its MSB is bit shift + w - 1
-    const unsigned long long neww = oldw | (tag << shift);
+    const uint2 B1 = tab2[b1], B2 = tab2[b2];
+    uint32_t found, f1, f2;
+    if (w21) {
+      const uint32_t a0 = B1.x & M21, a1 = __builtin_amdgcn_alignbit(B1.y, B1.x, 21) & M21, a2 = (B1.y >> 10) & M21;
+      const uint32_t c0 = B2.x & M21, c1 = __builtin_amdgcn_alignbit(B2.y, B2.x, 21) & M21, c2 = (B2.y >> 10) & M21;
+      found = min(min(min(a0 ^ t1, a1 ^ t1), a2 ^ t1), min(min(c0 ^ t2, c1 ^ t2), c2 ^ t2)) == 0u ? 1u : 0u;
+      f1 = min(a0, 1u) + min(a1, 1u) + min(a2, 1u);
+      f2 = min(c0, 1u) + min(c1, 1u) + min(c2, 1u);
+    } else {
+      found = min(min(B1.x ^ t1, B1.y ^ t1), min(B2.x ^ t2, B2.y ^ t2)) == 0u ? 1u : 0u;
+      f1 = min(B1.x, 1u) + min(B1.y, 1u);
+      f2 = min(B2.x, 1u) + min(B2.y, 1u);
+    }
+    const uint32_t cap = w21 ? 3u : 2u;
+    const uint32_t full = min(f1, f2) == cap ? 1u : 0u;
+    const bool first = f1 <= f2;  // insert into the emptier bucket
+    const uint32_t f = first ? f1 : f2, tag = first ? t1 : t2;
+    const uint2 oldw = first ? B1 : B2;
+    uint2 neww = oldw;
+    if (w21) {  // field f of {hi, lo}: shift the tag left by 21 f
+      neww.x |= f == 0u ? tag : f == 1u ? tag << 21 : 0u;
+      neww.y |= f == 1u ? tag >> 11 : f == 2u ? tag << 10 : 0u;
+    } else {
+      neww.x |= f == 0u ? tag : 0u;
+      neww.y |= f == 1u ? tag : 0u;
+    }
+    const unsigned long long old64 = ((unsigned long long)oldw.y << 32) | oldw.x;
+    const unsigned long long new64 = ((unsigned long long)neww.y << 32) | neww.x;
     const uint32_t try_cas = pending & (found ^ 1u) & (full ^ 1u);
-    unsigned long long got = ~oldw;
-    if (try_cas) got = atomicCAS(tab + (first ? b1 : b2), oldw, neww);
-    const uint32_t won = try_cas & (got == oldw ? 1u : 0u);
+    unsigned long long got = ~old64;
+    if (try_cas) got = atomicCAS(tab + (first ? b1 : b2), old64, new64);
+    const uint32_t won = try_cas & (got == old64 ? 1u : 0u);
     isnew |= won;
     const uint32_t to_bitmap = pending & (found ^ 1u) & full;
     if (__ballot(to_bitmap != 0u) != 0ull) {
