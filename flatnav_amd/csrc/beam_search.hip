@@ -113,27 +113,33 @@ hipError_t raise_lds_limit(const void* kern, int device, uint32_t bytes) {
 // ---- kernel lookup ----------------------------------------------------------------------------------------------
 #ifdef FNV_DEV_FAST_BUILD
 // Developer builds (-DFNV_DEV_FAST_BUILD): ONE translation unit, ONE instantiation per kernel -- element type
-// FNV_DEV_T, L2, G = 8, CU = FNV_DEV_CU, FULL rows -- compiles in seconds (float/4: 128-d f32 rows; unsigned char/1:
-// 128-d u8 rows).  Every table slot points at it.
+// FNV_DEV_T, metric FNV_DEV_METRIC, G = FNV_DEV_G, CU = FNV_DEV_CU, FULL rows -- compiles in seconds (float/8/4: 128-d f32
+// rows; unsigned char/8/1: 128-d u8 rows; float/64/3 with FNV_METRIC_IP: 768-d inner product).  Every table slot points at it.
 #ifndef FNV_DEV_T
 #define FNV_DEV_T float
 #endif
 #ifndef FNV_DEV_CU
 #define FNV_DEV_CU 4
 #endif
+#ifndef FNV_DEV_G
+#define FNV_DEV_G 8
+#endif
+#ifndef FNV_DEV_METRIC
+#define FNV_DEV_METRIC FNV_METRIC_L2
+#endif
 const KernelTable& kernel_table(int, int) {
   static KernelTable t = [] {
     KernelTable k;
     for (int c = 0; c < kNumCfgs; c++)
       for (int f = 0; f < 2; f++) {
-        k.exact[c][f] = beam_search_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
-        k.scan[c][f] = entry_scan_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
-        k.merged[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, MB_R>;
-        k.merged1[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, 1>;
-        k.merged0[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, 0>;
-        k.merged2[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true, 2>;
-        k.select[c][f] = wire_select_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
-        k.connect[c][f] = wire_connect_kernel<FNV_DEV_T, FNV_METRIC_L2, 8, FNV_DEV_CU, true>;
+        k.exact[c][f] = beam_search_kernel<FNV_DEV_T, FNV_DEV_METRIC, FNV_DEV_G, FNV_DEV_CU, true>;
+        k.scan[c][f] = entry_scan_kernel<FNV_DEV_T, FNV_DEV_METRIC, FNV_DEV_G, FNV_DEV_CU, true>;
+        k.merged[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_DEV_METRIC, FNV_DEV_G, FNV_DEV_CU, true, MB_R>;
+        k.merged1[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_DEV_METRIC, FNV_DEV_G, FNV_DEV_CU, true, 1>;
+        k.merged0[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_DEV_METRIC, FNV_DEV_G, FNV_DEV_CU, true, 0>;
+        k.merged2[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_DEV_METRIC, FNV_DEV_G, FNV_DEV_CU, true, 2>;
+        k.select[c][f] = wire_select_kernel<FNV_DEV_T, FNV_DEV_METRIC, FNV_DEV_G, FNV_DEV_CU, true>;
+        k.connect[c][f] = wire_connect_kernel<FNV_DEV_T, FNV_DEV_METRIC, FNV_DEV_G, FNV_DEV_CU, true>;
       }
     return k;
   }();

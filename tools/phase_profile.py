@@ -24,14 +24,19 @@ def main():
     ap.add_argument("--ef", type=int, default=100)
     ap.add_argument("--build-only", action="store_true")
     ap.add_argument("--dtype", default="float32", choices=["float32", "uint8"], help="element type of the 128-d index")
+    ap.add_argument("--dim768", action="store_true", help="768-d float32 inner product on low-rank unit vectors (config C3's shape)")
     ap.add_argument("--opt", action="append", default=[])
     args = ap.parse_args()
     from flatnav_amd import build as hb
 
     prof_lib = PROF_LIB if args.dtype == "float32" else PROF_LIB.replace(".so", "_u8.so")
+    if args.dim768:
+        prof_lib = PROF_LIB.replace(".so", "_768.so")
     if not os.path.exists(prof_lib) or args.build_only:
         # one instantiation only: float / L2 / 128-d (G=8, CU=4), or uint8 / L2 / 128-d (G=8, CU=1)
         extra = [] if args.dtype == "float32" else ["FNV_DEV_T=uint8_t", "FNV_DEV_CU=1"]
+        if args.dim768:
+            extra = ["FNV_DEV_G=64", "FNV_DEV_CU=3", "FNV_DEV_METRIC=FNV_METRIC_IP"]
         hb.build(force=True, defines=["FNV_PHASE_TIMING", "FNV_DEV_FAST_BUILD"] + extra, out=prof_lib)
     if args.build_only:
         return
@@ -42,16 +47,20 @@ def main():
     from flatnav_amd import datasets as ds
     from flatnav_amd import hip
 
-    X, Q = ds.sift_like(args.n, args.nq)
+    DIM, metric = (768, "angular") if args.dim768 else (128, "l2")
+    if args.dim768:
+        X, Q = ds.lowrank_normalized(args.n, args.nq, dim=768, rank=32, seed=7712)
+    else:
+        X, Q = ds.sift_like(args.n, args.nq)
     if args.dtype == "uint8":
         X, Q = X.astype(np.uint8), Q.astype(np.uint8)
-    index = flatnav.index.create("l2", 128, args.n, 32, getattr(flatnav.data_type.DataType, args.dtype))
+    index = flatnav.index.create(metric, DIM, args.n, 32, getattr(flatnav.data_type.DataType, args.dtype))
     index.set_num_threads(min(24, os.cpu_count()))
     t0 = time.time()
     index.add(X, 100, device=True)
     print("build %.1fs" % (time.time() - t0), flush=True)
     dev = hip.DeviceIndex.upload(np.asarray(index._raw_blob()), index._node_size_bytes, index._data_size_bytes, 32,
-                                 args.n, args.dtype, "l2", 128)
+                                 args.n, args.dtype, metric, DIM)
     for o in args.opt:
         k, v = o.split("=")
         dev.set_option(k, int(v))
