@@ -68,6 +68,23 @@ def test_two_ranks_share_one_gpu_over_gloo():
     assert d["config"]["recall_at_10"] >= 0.95 and d["value"] > 0
 
 
+def test_two_ranks_also_run_the_multi_gpu_configuration():
+    # with N > 1 GPUs the default line carries c5 (the configuration worded for 8 GPUs) after the main one: every rank
+    # takes part in its broadcast, ef agreement and timing barriers (here at a test size, two ranks on the one GPU)
+    env = dict(os.environ, BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL + [
+               "--secondary-configs", "c5", "--secondary-index-size", "40000"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["workload"].startswith("c2 ")
+    e = d["c5"]
+    assert e["n_gpus"] == 2 and e["config"]["workload"].startswith("c5 ") and e["value"] > 0
+    assert e["config"]["parallelism"].startswith("index replicated x2") and "cpu_baseline" not in e
+    assert any(x.get("config") == "c5" for x in d["secondary"])
+
+
 def test_benchmark_harness_writes_the_reference_metrics(tmp_path):
     # tools/run_benchmark.py: the reference's harness metrics (experiments/run-benchmark.py:38-124: recall, qps,
     # latency percentiles, distance computations per query) for the GPU index, written as metrics.json
