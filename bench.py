@@ -272,7 +272,19 @@ def main() -> None:
         dist.destroy_process_group()
     if rank == 0:
         out["bench_wall_seconds"] = round(time.time() - t_start, 1)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(compact(out), separators=(",", ":")), flush=True)
+
+
+def compact(obj, top=True):
+    """The line carries five configurations: floats below the top level are rounded to six significant digits (the
+    contract fields keep every digit) so that it stays a line (~14 KB)."""
+    if isinstance(obj, dict):
+        return {k: (v if top and k in ("value", "ms_per_step") else compact(v, False)) for k, v in obj.items()}
+    if isinstance(obj, list):
+        return [compact(v, False) for v in obj]
+    if isinstance(obj, float) and obj == obj and abs(obj) not in (0.0, float("inf")):
+        return float("%.6g" % obj)
+    return obj
 
 
 def run_config(ctx, args, config, main_line):
@@ -596,11 +608,17 @@ def run_config(ctx, args, config, main_line):
             "sustained": sustained,
             "pipelined": pipelined,
         }
-        if not main_line:
+        if not main_line:  # a further configuration's entry: the notes that repeat the main line's are dropped
             out.pop("sustained")
             out["ef_lines"] = out.pop("secondary")
+            out["config"].pop("measured_in_this_run")
+            out["roofline"].pop("gather_ceiling_note")
+            if out.get("pipelined"):
+                out["pipelined"].pop("note")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(index, dev, Q_rank[0], K, EF, hw, DT, metric, seconds=8.0 if main_line else 5.0)
+            if not main_line:  # (the host is described once, in the main line's sample)
+                out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"].split("; host:")[0]
     # ---- give everything back before the next configuration ----------------------------------------------------------
     dev.close()
     del dev, index, dq, d_dist, d_lab, d_cnt, d_nd, d_nh, gt, data, Q_all, Q_rank

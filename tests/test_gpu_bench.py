@@ -30,7 +30,7 @@ def test_single_gpu_line_has_the_contract_fields():
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dtype"] == "f32"
     assert d["config"]["recall_at_10"] >= 0.95 and "workload" in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5  # (floats below the top level carry six digits)
     assert r["gather_ceiling"] > r["achieved"] > 0 and 0 < r["frac_of_gather_ceiling"] < 1  # pure gather beats gather + search
     assert r["algorithmic_bytes_per_launch"] <= r["line_bytes_per_launch"]
     c = d["cpu_baseline"]
