@@ -206,7 +206,9 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
         }
         if (r1 < 0) break;  // every beam member expanded: what is left in the reference's queue is stale
         node = lane_of(ir, r1, l1);
+#ifndef FNV_LATE_ROW
         row0 = lane < M ? links[(uint64_t)(uint32_t)node * (uint32_t)M + lane] : EMPTY_ID;
+#endif
         key_c = lane_of(kr, r1, l1);
         if (r2 >= 0 && lane_of(kr, r2, l2) == key_c) pend = fmaxf(pend, key_c);
 #pragma unroll
@@ -219,7 +221,9 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
         const int c0 = cur;
         fnv_stl::Entry w = unpack(beam[min(c0 + lane, n - 1)]);
         node = __builtin_amdgcn_readlane((int)w.val, 0);
+#ifndef FNV_LATE_ROW
         row0 = lane < M ? links[(uint64_t)(uint32_t)node * (uint32_t)M + lane] : EMPTY_ID;
+#endif
         key_c = readlane_f(w.key, 0);
         int c2 = NO_ENTRY;
         for (int base = c0;;) {
@@ -250,6 +254,9 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
       }
       n_hops++;
       PH_MARK(2);
+#ifdef FNV_LATE_ROW  // (experiment knob: the round-2 placement of the load, after the tie bookkeeping)
+      row0 = lane < M ? links[(uint64_t)(uint32_t)node * (uint32_t)M + lane] : EMPTY_ID;
+#endif
       PH_MARK(3);
 
       // One 64-link chunk of the row: visited test-and-mark, gather + distances of the new ones, merge.  Returns false
