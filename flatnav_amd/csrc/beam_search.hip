@@ -704,7 +704,7 @@ static uint32_t lay_out(const fnv_index_s* ix, SearchParams& p, uint32_t slots, 
   p.off_stage_ids = off;
   off = align16(off + (WAVE + 1) * 4);  // + one write-only slot for lanes with nothing to stage
   p.off_ovf = off;
-  off = align16(off + (OVF_LIST + 2) * 4);
+  off = align16(off + (OVF_LIST + 2 + STASH) * 4);
   return off;
 }
 
@@ -1400,9 +1400,11 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
       }
     }
   }
+  const bool tune_log = getenv("FLATNAV_TUNE_LOG") != nullptr;  // developer aid: every measurement on stderr
   size_t best_layout = 0;
   float best_layout_t = -1.f;
-  for (size_t li = 0; li < cands.size(); li++) {
+  // one layout's time: the better of the merged-beam kernel alone and with 75 % of its last round straight to the exact search
+  auto time_layout = [&](size_t li, float* out) -> int {
     {
       std::lock_guard<std::mutex> lock(ix->mu);
       if (li == 0) ix->layouts.erase(B);
@@ -1410,14 +1412,44 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
       ix->plan.valid = false;
     }
     float t1 = -1.f, t4 = -1.f;
-    if (time_variant(1, 4, &t1) != FNV_OK) continue;  // e.g. a layout that does not fit LDS: not a candidate
+    int r = time_variant(1, 4, &t1);
+    if (r) return r;
     const bool multi = nq > (uint64_t)ix->plan.sbpc * (uint64_t)ix->num_cus;
-    if (multi && ix->sorted_tail_exact_pct < 0 && time_variant(3, 4, &t4) != FNV_OK) continue;
-    const float t = (t4 > 0.f && t4 < t1) ? t4 : t1;
+    if (multi && ix->sorted_tail_exact_pct < 0 && (r = time_variant(3, 4, &t4)) != FNV_OK) return r;
+    *out = (t4 > 0.f && t4 < t1) ? t4 : t1;
+    if (tune_log)
+      fprintf(stderr, "fnv_tune B=%d layout %zu (heap in LDS %d, table %u): merged %.4f ms, 75%% tail exact %.4f ms -> %u slots, %d per CU\n", B,
+              li, (int)cands[li].cand_lds, cands[li].vis_slots, t1 * (float)nq, t4 * (float)nq, (unsigned)ix->geom[4], (int)ix->geom[3]);
+    return FNV_OK;
+  };
+  // The device settles first.  After the GPU has idled (the caller computed something on the host) the first launches run
+  // up to 70 % slower than the steady state, for about 0.3 s of work -- clocks and power state (measured inside bench.py:
+  // the rules' layout, timed first, lost to a neighbour it beats by 10 %; launches of 8.3 ms that take 4.8 ms half a second
+  // later).  The slow state is steady while it lasts, so "two launches agree" does not end it: launches repeat for half a
+  // second, then until two in a row agree.
+  {
+    const auto t_begin = std::chrono::steady_clock::now();
+    float prev = -1.f;
+    for (int i = 0; i < 400; i++) {
+      float t = 0.f;
+      if (time_variant(1, 1, &t) != FNV_OK) break;
+      const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+      if (tune_log) fprintf(stderr, "fnv_tune B=%d settling: %.4f ms (at %.2f s)\n", B, t * (float)nq, waited);
+      if ((waited > 0.5 && prev > 0.f && fabsf(t - prev) < 0.02f * prev) || waited > 2.0) break;
+      prev = t;
+    }
+  }
+  for (size_t li = 0; li < cands.size(); li++) {
+    float t = -1.f;
+    if (time_layout(li, &t) != FNV_OK) continue;  // e.g. a layout that does not fit LDS: not a candidate
     if (best_layout_t < 0.f || t < best_layout_t * 0.98f) {  // a neighbour must win by more than noise
       best_layout_t = t;
       best_layout = li;
     }
+  }
+  if (best_layout != 0) {  // a neighbour won: the rules' layout was timed first, so it is timed once more, now last
+    float again = -1.f;
+    if (time_layout(0, &again) == FNV_OK && !(best_layout_t < again * 0.98f)) best_layout = 0;
   }
   {
     std::lock_guard<std::mutex> lock(ix->mu);
@@ -1436,6 +1468,7 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
   for (int v = 0; v < nvar; v++) {
     rc = time_variant(v, 4, &t.best[v]);
     if (rc) return rc;
+    if (tune_log) fprintf(stderr, "fnv_tune B=%d variant %d: %.4f ms\n", B, v, t.best[v] * (float)nq);
     t.samples[v] = 4;  // settled: later launches neither explore nor sample
   }
   {

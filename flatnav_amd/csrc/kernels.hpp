@@ -115,6 +115,8 @@ __device__ __forceinline__ void reset_visited(uint32_t* vis, uint32_t* ovf_list,
   const uint32_t n16 = cold_args()->vis_bytes / 16;
   for (uint32_t i = lane; i < n16; i += WAVE) v4[i] = make_uint4(fill, fill, fill, fill);
   if (lane == 0) ovf_list[0] = 0u;
+  static_assert(STASH <= (uint32_t)WAVE, "one store per lane empties the stash");
+  if ((uint32_t)lane < STASH) ovf_list[OVF_LIST + 2 + lane] = 0u;  // the stash is empty
 }
 
 template <typename T>

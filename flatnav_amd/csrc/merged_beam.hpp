@@ -182,11 +182,27 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
     float pend = -INF;  // (b) pending: largest key at which two unexpanded members tied
     bool pend_cut = false;  // ... and, while it is pending, equal keys met where the beam is cut (see the header)
     uint32_t n_dist = 0, n_hops = 0;
+    // Round 3: the link row of the RUNNER-UP is requested one hop ahead.  Once the beam has converged the next node to
+    // expand is most often the current runner-up (a new neighbour rarely lands in front of every unexpanded member), and
+    // then the hop starts with its link row already in a register: one dependent memory round trip per hop instead of
+    // two.  A wrong guess costs one 4*M-byte request for a row that is expanded soon after anyway (it stays in L2).
+    int spec_node = -1;
+    uint32_t spec_row = EMPTY_ID;
+    auto load_row = [&](const int nd) -> uint32_t { return lane < M ? links[(uint64_t)(uint32_t)nd * (uint32_t)M + lane] : EMPTY_ID; };
+    auto take_row = [&](const int nd) -> uint32_t { return nd == spec_node ? spec_row : load_row(nd); };
+    auto guess_next = [&](const int nd, const int runner_up) {
+#ifndef FNV_NO_SPEC_ROW
+      if (runner_up != spec_node || nd == spec_node) {  // (a guess that is still the runner-up keeps its row)
+        spec_node = runner_up;
+        if (runner_up >= 0) spec_row = load_row(runner_up);
+      }
+#endif
+    };
     __syncthreads();
 
     while (!tie) {
       // ---- pick the closest unexpanded member; (b) its runner-up must not have the same key -------------------
-      int node;
+      int node, runner_up = -1;
       float key_c;
       uint32_t row0;  // the node's link row: requested as soon as the node is known (round 3), ahead of the tie bookkeeping
       if constexpr (R > 0) {
@@ -206,9 +222,8 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
         }
         if (r1 < 0) break;  // every beam member expanded: what is left in the reference's queue is stale
         node = lane_of(ir, r1, l1);
-#ifndef FNV_LATE_ROW
-        row0 = lane < M ? links[(uint64_t)(uint32_t)node * (uint32_t)M + lane] : EMPTY_ID;
-#endif
+        row0 = take_row(node);
+        if (r2 >= 0) runner_up = lane_of(ir, r2, l2);
         key_c = lane_of(kr, r1, l1);
         if (r2 >= 0 && lane_of(kr, r2, l2) == key_c) pend = fmaxf(pend, key_c);
 #pragma unroll
@@ -221,9 +236,7 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
         const int c0 = cur;
         fnv_stl::Entry w = unpack(beam[min(c0 + lane, n - 1)]);
         node = __builtin_amdgcn_readlane((int)w.val, 0);
-#ifndef FNV_LATE_ROW
-        row0 = lane < M ? links[(uint64_t)(uint32_t)node * (uint32_t)M + lane] : EMPTY_ID;
-#endif
+        row0 = take_row(node);
         key_c = readlane_f(w.key, 0);
         int c2 = NO_ENTRY;
         for (int base = c0;;) {
@@ -231,6 +244,7 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
           if (un) {
             const int l2 = __ffsll((long long)un) - 1;
             c2 = base + l2;
+            runner_up = __builtin_amdgcn_readlane((int)w.val, l2);
             if (readlane_f(w.key, l2) == key_c) pend = fmaxf(pend, key_c);
             break;
           }
@@ -254,9 +268,6 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
       }
       n_hops++;
       PH_MARK(2);
-#ifdef FNV_LATE_ROW  // (experiment knob: the round-2 placement of the load, after the tie bookkeeping)
-      row0 = lane < M ? links[(uint64_t)(uint32_t)node * (uint32_t)M + lane] : EMPTY_ID;
-#endif
       PH_MARK(3);
 
       // One 64-link chunk of the row: visited test-and-mark, gather + distances of the new ones, merge.  Returns false
@@ -267,6 +278,9 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
         bool isnew;
         if (vg.w == 16) isnew = visited_insert_tag16(vis, vg, act, id, bitmap, ovf_list, ovf_glist, ovf);
         else isnew = visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), vg, act, id, bitmap, ovf_list, ovf_glist, ovf);
+        // the guess is requested HERE: after the node's own row has been consumed (the wait for that row is a wait for
+        // every request in flight, so a guess issued earlier would be waited for as well) and ahead of the gathers
+        if (m0 == 0) guess_next(node, runner_up);
         const unsigned long long newmask = __ballot(isnew);
         const int nn = __popcll(newmask);
         stage_ids[isnew ? __popcll(newmask & ((1ull << lane) - 1ull)) : WAVE] = id;  // keeps link order

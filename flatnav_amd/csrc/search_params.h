@@ -54,6 +54,12 @@ enum : int { ST_OK = 0, ST_CAND_OVERFLOW = 1 };
 constexpr int SCAN_WAVES = 4;  // entry_scan_kernel (K0): waves per workgroup ...
 constexpr int SCAN_QPB = 32;   // ... and queries per workgroup
 constexpr uint32_t OVF_LIST = 30;  // ids remembered for a cheap clean-up of the HBM visited bitmap
+// Round 3: a STASH of full ids behind the tag table (the "stash" of cuckoo hashing): an id whose two buckets are both full
+// goes there first, and only when its stash bucket is full as well to the slot's HBM bitmap (visited.hpp).  At the load
+// factors the layouts run at (40-65 %) a query overflows a few dozen ids: with the stash they never leave LDS, and a
+// smaller table -- more resident queries -- no longer pays a dependent HBM round trip for them.  LDS: STASH words
+// after the overflow list, at [OVF_LIST + 2 ...).
+constexpr uint32_t STASH = 64;
 
 struct SearchParams {
   const uint8_t* vectors;   // [n_nodes][row_bytes]
@@ -88,7 +94,7 @@ struct SearchParams {
   uint32_t vis_bytes;      // LDS bytes of the table
   uint32_t vis_nmask, vis_rshift, vis_rmask;  // tag16: 2^nbits-1, t = nbits-k, 2^t-1
   uint32_t vis_mult;       // tag16: buckets = vis_mult * 2^k with vis_mult in {1, 3}
-  uint32_t off_ovf;        // LDS: [0] count, [1..OVF_LIST] ids that went to the HBM bitmap
+  uint32_t off_ovf;        // LDS: [0] count, [1..OVF_LIST] ids that went to the HBM bitmap, [OVF_LIST + 2 ...) the stash
   uint32_t cand_slots, spill_entries, bitmap_words, ovf_cap;
   uint32_t off_q, off_nbr, off_cand, off_vis, off_stage_ids;
   uint32_t off_stage_d;     // LDS: [WAVE + 1] distances of a link row's unvisited neighbours (merged-beam kernel; = off_nbr:

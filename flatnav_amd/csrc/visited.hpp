@@ -56,6 +56,42 @@ __device__ __forceinline__ void tag16_slot(const VisGeom& g, uint32_t h, uint32_
   tag = (rem << 1) + 1u + which;
 }
 
+// The stash (search_params.h): lanes whose id found both its buckets full come here before the HBM bitmap (a wave-uniform
+// branch around the call: rare).  A second, tiny table of FULL ids: STASH / 4 buckets of four (one 16-byte LDS read), the
+// bucket chosen by a third hash; an id is looked up in its bucket, else put into the bucket's first free word (stored as
+// id + 1, 0 = free), else -- bucket full -- left to the bitmap.  Nothing is ever removed, so "its stash bucket is full ->
+// the bitmap decides" stays true for the rest of the query, exactly like "both table buckets full -> the stash decides":
+// the three places stay consistent.  All lanes work at once (~30 instructions per call; a first version that compared one
+// lane's id at a time against a fully associative stash cost ~50-100 per call and lost 10 % on 50M x 128 Gaussian rows,
+// where queries sit for long with a nearly full stash).
+__device__ __forceinline__ void visited_stash(uint32_t* ovf_list, uint32_t& to_bitmap, uint32_t id, uint32_t& isnew) {
+#ifdef FNV_NO_STASH  // (experiment knob: every overflow straight to the bitmap, as in round 2)
+  return;
+#endif
+  static_assert((STASH & (STASH - 1)) == 0 && STASH >= 8, "STASH / 4 buckets, a power of two");
+  uint32_t* const bucket = ovf_list + OVF_LIST + 2 + 4u * ((id * 0xC2B2AE35u) >> (32 - (31 - __builtin_clz(STASH / 4))));
+  const uint32_t key = id + 1u;
+  uint32_t pend = to_bitmap;
+  while (__ballot(pend != 0u) != 0ull) {
+    const uint4 e = *reinterpret_cast<const uint4*>(bucket);
+    const bool found = e.x == key || e.y == key || e.z == key || e.w == key;
+    const int free_at = e.x == 0u ? 0 : e.y == 0u ? 1 : e.z == 0u ? 2 : e.w == 0u ? 3 : -1;
+    if (pend && found) {
+      to_bitmap = 0u;  // seen before
+      pend = 0u;
+    } else if (pend && free_at < 0) {
+      pend = 0u;  // bucket full: the bitmap decides
+    } else if (pend) {
+      const uint32_t old = atomicCAS(bucket + free_at, 0u, key);
+      if (old == 0u || old == key) {  // (old == key: another lane of this row holds the same id and was first)
+        isnew |= old == 0u ? 1u : 0u;
+        to_bitmap = 0u;
+        pend = 0u;
+      }  // else: another id took the word -- look again
+    }
+  }
+}
+
 // Called by ALL lanes (inactive ones pass act = false).  The probe is straight-line arithmetic (bitwise, no
 // short-circuit branches) inside a wave-uniform retry loop that normally runs once, so EXEC is only touched
 // around the CAS itself -- the scalar unit that manipulates EXEC is shared by every wave of the CU.
@@ -108,7 +144,8 @@ __device__ __forceinline__ bool visited_insert_tag16(uint32_t* tab, const VisGeo
     if (try_cas) got = atomicCAS(tab + 2 * (first ? b1 : b2) + (f >> 1), oldw, neww);
     const uint32_t won = try_cas & (got == oldw ? 1u : 0u);
     isnew |= won;
-    const uint32_t to_bitmap = pending & (found ^ 1u) & full;  // both buckets full: the HBM bitmap decides (rare)
+    uint32_t to_bitmap = pending & (found ^ 1u) & full;  // both buckets full: the stash, then the HBM bitmap decides (rare)
+    if (__ballot(to_bitmap != 0u) != 0ull) visited_stash(ovf_list, to_bitmap, id, isnew);
     if (__ballot(to_bitmap != 0u) != 0ull) {
       used_bitmap = true;  // wave-uniform: set for every lane as soon as any lane's id goes to the bitmap
       if (to_bitmap) {
@@ -182,7 +219,8 @@ __device__ __forceinline__ bool visited_insert_tagw(unsigned long long* tab, con
     if (try_cas) got = atomicCAS(tab + (first ? b1 : b2), old64, new64);
     const uint32_t won = try_cas & (got == old64 ? 1u : 0u);
     isnew |= won;
-    const uint32_t to_bitmap = pending & (found ^ 1u) & full;
+    uint32_t to_bitmap = pending & (found ^ 1u) & full;
+    if (__ballot(to_bitmap != 0u) != 0ull) visited_stash(ovf_list, to_bitmap, id, isnew);
     if (__ballot(to_bitmap != 0u) != 0ull) {
       used_bitmap = true;  // wave-uniform: set for every lane as soon as any lane's id goes to the bitmap
       if (to_bitmap) {

@@ -26,18 +26,22 @@ def main():
     ap.add_argument("--dtype", default="float32", choices=["float32", "uint8"], help="element type of the 128-d index")
     ap.add_argument("--dim768", action="store_true", help="768-d float32 inner product on low-rank unit vectors (config C3's shape)")
     ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--define", action="append", default=[], help="extra -D for the profiling build (e.g. FNV_NO_SPEC_ROW)")
+    ap.add_argument("--tag", default="", help="suffix of the profiling library's file name (one per set of --define)")
     args = ap.parse_args()
     from flatnav_amd import build as hb
 
     prof_lib = PROF_LIB if args.dtype == "float32" else PROF_LIB.replace(".so", "_u8.so")
     if args.dim768:
         prof_lib = PROF_LIB.replace(".so", "_768.so")
+    if args.tag:
+        prof_lib = prof_lib.replace(".so", "_%s.so" % args.tag)
     if not os.path.exists(prof_lib) or args.build_only:
         # one instantiation only: float / L2 / 128-d (G=8, CU=4), or uint8 / L2 / 128-d (G=8, CU=1)
         extra = [] if args.dtype == "float32" else ["FNV_DEV_T=uint8_t", "FNV_DEV_CU=1"]
         if args.dim768:
             extra = ["FNV_DEV_G=64", "FNV_DEV_CU=3", "FNV_DEV_METRIC=FNV_METRIC_IP"]
-        hb.build(force=True, defines=["FNV_PHASE_TIMING", "FNV_DEV_FAST_BUILD"] + extra, out=prof_lib)
+        hb.build(force=True, defines=["FNV_PHASE_TIMING", "FNV_DEV_FAST_BUILD"] + extra + args.define, out=prof_lib)
     if args.build_only:
         return
     os.environ["FLATNAV_HIP_LIB"] = prof_lib
