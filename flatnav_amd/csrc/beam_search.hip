@@ -1354,7 +1354,9 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
     size_t bytes = 768u << 20;
     ~Flush() { if (p) (void)hipFree(p); }
   } flush;
-  if (hipMalloc(&flush.p, flush.bytes) != hipSuccess) flush.p = nullptr;  // (no room: tune warm, as before)
+  const char* flush_env = getenv("FLATNAV_TUNE_FLUSH");  // developer knob: 0 = time warm launches
+  if (flush_env && flush_env[0] == '0') flush.p = nullptr;
+  else if (hipMalloc(&flush.p, flush.bytes) != hipSuccess) flush.p = nullptr;  // (no room: tune warm, as before)
   (void)hipGetLastError();
   // mean of `reps` timed launches of one variant, each on another rotation of the batch (after a cold launch), ms per query
   auto time_variant = [&](int v, int reps, float* out) -> int {
