@@ -190,8 +190,8 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
     uint32_t spec_row = EMPTY_ID;
     auto load_row = [&](const int nd) -> uint32_t { return lane < M ? links[(uint64_t)(uint32_t)nd * (uint32_t)M + lane] : EMPTY_ID; };
     auto take_row = [&](const int nd) -> uint32_t { return nd == spec_node ? spec_row : load_row(nd); };
-    // (not for 1-byte elements: their hop is bound by instruction issue, not by latency, and the ~15 instructions of the
-    // guess cost the uint8 index 3 % -- SQ counters in profiles/r3_sq_counters.json)
+    // (not for 1-byte elements: their hop is bound by instruction issue, not by latency -- the guess bought the uint8 index
+    // nothing and cost ~20 M scalar instructions per launch, 162 -> 143 M in profiles/r3_sq_counters.json)
     auto guess_next = [&](const int nd, const int runner_up) {
 #ifndef FNV_NO_SPEC_ROW
       if constexpr (sizeof(T) > 1) {
