@@ -67,7 +67,13 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str | Non
     custom = bool(defines) or out != LIB  # profiling / experiment builds get their own object directory
     if not force and not custom and not needs_build():
         return LIB
-    objdir = OBJ if not custom else OBJ + "_" + "_".join(sorted(d.replace("=", "-") for d in defines))[:80]
+    if custom:  # its own object directory: readable prefix + a hash of the whole define set and the output (no collisions)
+        import hashlib
+
+        tag = "_".join(sorted(d.replace("=", "-") for d in defines))
+        objdir = OBJ + "_" + tag[:60] + "_" + hashlib.sha1((tag + "|" + out).encode()).hexdigest()[:10]
+    else:
+        objdir = OBJ
     os.makedirs(objdir, exist_ok=True)
     base = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
             "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include")]

@@ -226,7 +226,8 @@ struct fnv_index_s : IndexOptions {
   int device = 0;
   int dtype = FNV_DTYPE_FLOAT32, metric = FNV_METRIC_L2;
   uint32_t M = 0, dim = 0, row_bytes = 0;
-  uint64_t n_nodes = 0;   // live nodes: what a search sees (entry scan, id range)
+  std::atomic<uint64_t> n_nodes{0};  // live nodes: what a search sees (entry scan, id range); a view reads its source's at
+                                     // every launch while the source may be growing -> atomic
   uint64_t capacity = 0;  // rows the device buffers hold (>= n_nodes; grows never)
   uint8_t* d_vectors = nullptr;
   uint32_t* d_links = nullptr;
@@ -249,7 +250,6 @@ struct fnv_index_s : IndexOptions {
   std::map<int, LayoutChoice> layouts;
   std::map<int, Tuner> tuner;
   int sample_B = 0, sample_kernel = -1;  // the launch between ev0 / ev1 is a sample for this entry (-1: it is not)
-  int force_variant = -1;                // fnv_tune: the variant the next launch must run (-1: none)
   uint64_t sample_nq = 0;
   int last_variant = 0;          // what the most recent launch ran: 0 two-heap kernel, 1 merged beam, 2-4 with exact tail
   bool last_exploratory = false;  // ... and whether the adaptive choice was still sampling (not its final pick)
@@ -476,7 +476,7 @@ int fnv_index_view(fnv_index_t src, fnv_index_t* out) {
   v->M = src->M;
   v->dim = src->dim;
   v->row_bytes = src->row_bytes;
-  v->n_nodes = src->n_nodes;
+  v->n_nodes = src->n_nodes.load();
   v->capacity = src->capacity;
   v->d_vectors = src->d_vectors;
   v->d_links = src->d_links;
@@ -499,6 +499,40 @@ int fnv_index_view(fnv_index_t src, fnv_index_t* out) {
   return FNV_OK;
 }
 
+int fnv_index_adopt(const void* vectors, const void* links, const void* labels, uint32_t M, uint64_t n_nodes, int data_type,
+                    int metric, uint32_t dim, int device, fnv_index_t* out) {
+  if (!vectors || !links || !labels || !out) return fail(FNV_ERR_INVALID, "null argument");
+  int rc = validate_geometry(M, n_nodes, data_type, metric, dim);
+  if (rc) return rc;
+  if (((uintptr_t)vectors & 15u) || ((uintptr_t)links & 3u) || ((uintptr_t)labels & 3u))
+    return fail(FNV_ERR_INVALID, "fnv_index_adopt: vectors must be 16-byte aligned, links and labels 4-byte aligned");
+  fnv_index_s* v = new fnv_index_s();
+  v->owns_buffers = false;
+  v->device = device;
+  v->dtype = data_type;
+  v->metric = metric;
+  v->M = M;
+  v->dim = dim;
+  v->row_bytes = row_stride_bytes(dim, data_type);
+  v->n_nodes = n_nodes;
+  v->capacity = n_nodes;
+  v->d_vectors = (uint8_t*)const_cast<void*>(vectors);
+  v->d_links = (uint32_t*)const_cast<void*>(links);
+  v->d_labels = (int32_t*)const_cast<void*>(labels);
+  DeviceScope scope(device);
+  if (scope.err != hipSuccess) {
+    delete v;
+    return fail(FNV_ERR_NO_DEVICE, "hipSetDevice failed");
+  }
+  rc = index_common_init(v);
+  if (rc) {
+    fnv_index_free(v);
+    return rc;
+  }
+  *out = v;
+  return FNV_OK;
+}
+
 int fnv_index_device_buffers(fnv_index_t ix, void* ptrs[3], uint64_t sizes[3]) {
   if (!ix || !ptrs || !sizes) return fail(FNV_ERR_INVALID, "null argument");
   ptrs[0] = ix->d_vectors;
@@ -515,7 +549,7 @@ int fnv_index_info(fnv_index_t ix, uint64_t info[8]) {
   info[0] = (uint64_t)ix->dtype;
   info[1] = ix->M;
   info[2] = ix->row_bytes;
-  info[3] = ix->parent ? ix->parent->n_nodes : ix->n_nodes;
+  info[3] = ix->parent ? ix->parent->n_nodes.load() : ix->n_nodes.load();
   info[4] = ix->dim;
   info[5] = (uint64_t)ix->metric;
   info[6] = (uint64_t)ix->device;
@@ -630,17 +664,24 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   else if (n == "tune_layout") ix->tune_layout = value;
   else if (n == "shadow_exact") ix->shadow_exact = value;
   else return fail(FNV_ERR_INVALID, "unknown option: " + n);
-  ix->options_version++;
-  ix->tuner.clear();
-  ix->layouts.clear();
-  ix->sample_kernel = -1;
+  // What fnv_tune measured (kernel variant, LDS layout) stays valid across options that change neither the launch plan
+  // nor the kernel choice: Index.h::addBatchDevice flips output_node_ids around every device build, and a tune costs
+  // dozens of launches.  (output_node_ids is read per launch; shadow_exact per launch; tune_layout by fnv_tune itself.)
+  const bool keeps_tuning = n == "output_node_ids" || n == "shadow_exact" || n == "tune_layout";
+  if (!keeps_tuning) {
+    ix->options_version++;
+    ix->tuner.clear();
+    ix->layouts.clear();
+    ix->sample_kernel = -1;
+  }
   return FNV_OK;
 }
 
 // One batched search launch; node_ids: write node ids instead of labels (the device builder's beams).
 static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq, int K, int ef_search,
                               int num_initializations, float* d_out_dist, int32_t* d_out_labels, int32_t* d_out_count,
-                              uint64_t* d_out_ndist, uint64_t* d_out_nhops, void* hip_stream, bool node_ids);
+                              uint64_t* d_out_ndist, uint64_t* d_out_nhops, void* hip_stream, bool node_ids,
+                              int force_variant = -1);
 
 int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, int K, int ef_search,
                             int num_initializations, float* d_out_dist, int32_t* d_out_labels,
@@ -687,7 +728,7 @@ static uint32_t lay_out(const fnv_index_s* ix, SearchParams& p, uint32_t slots, 
   auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
   uint32_t off = 0;
   p.off_q = off;
-  off = align16(off + p.q_chunks * 16);
+  off = align16(off + p.q_lds_bytes);
   // neighbours heap (exact search) / sorted beam: arrays start at 16n + 8 so that child pairs are 16-byte aligned
   p.off_nbr = off + 8;
   // (merged-beam kernel: the same bytes stage a link row's distances, [WAVE + 1] floats, between two merges)
@@ -796,7 +837,9 @@ static int grow(void** buf, size_t* have, size_t need, bool zero = false) {
 
 static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq, int K, int ef_search,
                               int num_initializations, float* d_out_dist, int32_t* d_out_labels, int32_t* d_out_count,
-                              uint64_t* d_out_ndist, uint64_t* d_out_nhops, void* hip_stream, bool node_ids) {
+                              uint64_t* d_out_ndist, uint64_t* d_out_nhops, void* hip_stream, bool node_ids,
+                              int force_variant) {  // force_variant >= 0: fnv_tune's launches (an argument, not index state:
+                                                    // a concurrent caller's launch on the same handle is never forced)
   if (!ix) return fail(FNV_ERR_INVALID, "index is null");
   // Index.h:847-849
   if (num_initializations <= 0) return fail(FNV_ERR_INVALID, "num_initializations must be greater than 0.");
@@ -827,6 +870,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     const int cfg = pick_row_cfg(p.nchunks);
     const uint32_t per_iter = (uint32_t)(kCfgs[cfg].G * kCfgs[cfg].CU);
     p.q_chunks = (p.nchunks + per_iter - 1) / per_iter * per_iter;
+    p.q_lds_bytes = cfg_query_in_regs(cfg) ? 0u : p.q_chunks * 16u;
     p.cand_slots = ix->cand_slots ? (uint32_t)ix->cand_slots : (uint32_t)(ix->cand_factor * p.B + 192);
     p.cand_slots = std::max<uint32_t>(p.cand_slots, (uint32_t)p.B + 1);  // also hosts the final result list
     p.spill_entries = (uint32_t)ix->spill_entries;
@@ -914,7 +958,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   const bool multi_round = sorted && nq > round_slots;
   int64_t tail_pct = ix->sorted_tail_exact_pct < 0 ? 0 : ix->sorted_tail_exact_pct;
   bool exploratory = false;
-  const int pinned = ix->force_variant >= 0 ? ix->force_variant : (int)ix->sorted_variant;  // fnv_tune / "sorted_variant"
+  const int pinned = force_variant >= 0 ? force_variant : (int)ix->sorted_variant;  // fnv_tune / "sorted_variant"
   if (sorted && pinned >= 0) {
     variant = (pinned >= 2 && !multi_round) ? 1 : pinned;  // an exact tail needs more than one round of queries
     sorted = variant != 0;
@@ -976,7 +1020,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   p.out_count = d_out_count;
   p.out_ndist = d_out_ndist;
   p.out_nhops = d_out_nhops;
-  const uint64_t live = ix->parent ? ix->parent->n_nodes : ix->n_nodes;  // a view follows its source's growth
+  const uint64_t live = ix->parent ? ix->parent->n_nodes.load() : ix->n_nodes.load();  // a view follows its source's growth
   p.n_nodes = live;
   p.nq = (uint32_t)nq;
   // Index.h:851-861: step = max(1, N / n_init); nodes 0, step, 2*step, ... < N
@@ -1215,6 +1259,8 @@ int fnv_replica_refresh(fnv_index_t src, int n_replicas, fnv_index_t* replicas) 
     static_cast<IndexOptions&>(*r) = static_cast<const IndexOptions&>(*src);
     r->options_version++;
     r->tuner.clear();
+    r->layouts.clear();  // measured under the old options (a stale table size could even change the kernel mode)
+    r->plan.valid = false;
     r->sample_kernel = -1;
   }
   // Doubling tree of peer copies over xGMI: in every round each index that already holds the data feeds one that
@@ -1325,11 +1371,8 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
   const size_t qrow_bytes = (size_t)ix->dim * dtype_size(ix->dtype);
   uint8_t* o = (uint8_t*)ix->d_out;
   auto launch = [&](int variant, uint64_t rotate = 0) -> int {
-    ix->force_variant = variant;
-    const int rc = search_device_impl(ix, dq2 + (rotate % nq) * qrow_bytes, nq, K, ef_search, num_initializations, (float*)o,
-                                      (int32_t*)(o + o_lab), nullptr, nullptr, nullptr, ix->stream, ix->output_node_ids != 0);
-    ix->force_variant = -1;
-    return rc;
+    return search_device_impl(ix, dq2 + (rotate % nq) * qrow_bytes, nq, K, ef_search, num_initializations, (float*)o,
+                              (int32_t*)(o + o_lab), nullptr, nullptr, nullptr, ix->stream, ix->output_node_ids != 0, variant);
   };
   // what kind of launch is this?  (one probing launch of the merged-beam kernel tells: plan, round size)
   const int B = std::max(ef_search, K);
@@ -1492,7 +1535,7 @@ int fnv_gather_ceiling(fnv_index_t ix, int waves_per_cu, double* gbps_out) {
   if (!ix || !gbps_out) return fail(FNV_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lock(ix->mu);
   ON_DEVICE(ix->device);
-  const uint64_t n_rows = ix->parent ? ix->parent->n_nodes : ix->n_nodes;
+  const uint64_t n_rows = ix->parent ? ix->parent->n_nodes.load() : ix->n_nodes.load();
   const uint32_t nchunks = ix->row_bytes / 16;
   const int cfg = pick_row_cfg(nchunks);
   typedef void (*gather_fn)(const uint8_t*, uint64_t, uint32_t, int, uint32_t*);

@@ -115,7 +115,33 @@ template <int METRIC>
 struct Dist<int8_t, METRIC> : DistInt<int8_t, METRIC> {};
 
 // ---------------------------------------------------------------------------------------------
-// Distances from the query (in LDS, zero padded to q_chunks) to one BATCH of up to PU * (64/G) nodes.
+// Where a search keeps its query.  By default: staged in LDS, zero padded to q_chunks, read chunk by chunk inside the
+// distance loop.  Rows of exactly ONE 192-chunk span (G = 64, CU = 3: 768-d float32, 3 KB) keep it in REGISTERS instead
+// (round 4): lane g only ever multiplies with chunks g, g + 64, g + 128 of the query, which is 12 registers per lane and
+// gives the 3 KB of LDS per resident query back -- at 768-d the LDS is what bounds the queries in flight per CU, and the
+// queries in flight are what bound the bytes in flight (8 -> 10 per CU at ef = 800).  Same operands in the same order:
+// no distance changes.
+// ---------------------------------------------------------------------------------------------
+template <int G, int CU>
+constexpr bool query_in_regs() {
+  return G == 64 && CU == 3;  // (the host picks this row configuration only for rows of exactly G * CU chunks)
+}
+template <int G, int CU>
+struct Query {
+  const uint4* lds;                           // staged query; not read when the query lives in registers
+  uint4 r[query_in_regs<G, CU>() ? CU : 1];   // lane g: chunks g, g + G, ... of the query
+  // registers from a query that has been staged in LDS (kernels that stage many different vectors: K0, wiring)
+  __device__ __forceinline__ void from_lds(const uint4* staged, int lane) {
+    lds = staged;
+    if constexpr (query_in_regs<G, CU>()) {
+#pragma unroll
+      for (int cu = 0; cu < CU; cu++) r[cu] = staged[cu * G + lane % G];
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Distances from the query (in LDS, zero padded to q_chunks -- or in registers, above) to one BATCH of up to PU * (64/G) nodes.
 // Lane layout: g = lane % G walks the 16-byte chunks of a row (chunk g, g+G, ...), v = lane / G picks the
 // vector of a pass; pass pu holds batch slot pu*(64/G) + v.  id[pu] is per lane (equal within a G-lane group) and
 // must be a legal row for EVERY lane of passes < npass: callers give lanes beyond the last real slot the id of
@@ -127,7 +153,7 @@ struct Dist<int8_t, METRIC> : DistInt<int8_t, METRIC> {};
 // Rows are addressed as rows + id * row_stride: the HBM vector table in the search kernel, an LDS tile in the
 // entry-scan kernel (same arithmetic and summation order in both, so their distances agree bit for bit).
 template <typename T, int METRIC, int G, int CU, bool FULL>
-__device__ __forceinline__ void batch_dists(const uint8_t* rows, uint32_t row_stride, int nchunks, const uint4* qlds,
+__device__ __forceinline__ void batch_dists(const uint8_t* rows, uint32_t row_stride, int nchunks, const Query<G, CU>& q,
                                             const uint32_t (&id)[passes<G, CU>()], int npass, float (&out)[passes<G, CU>()], int lane) {
   constexpr int PU = passes<G, CU>();
   typedef Dist<T, METRIC> D;
@@ -158,7 +184,9 @@ __device__ __forceinline__ void batch_dists(const uint8_t* rows, uint32_t row_st
       }
 #pragma unroll
       for (int cu = 0; cu < CU; cu++) {
-        const uint4 x = qlds[c0 + cu * G + g];
+        uint4 x;
+        if constexpr (query_in_regs<G, CU>()) x = q.r[cu];  // (one span: c0 == 0)
+        else x = q.lds[c0 + cu * G + g];
         qacc = D::qchunk(qacc, x);
 #pragma unroll
         for (int pu = 0; pu < PU; pu++)
@@ -182,7 +210,9 @@ __device__ __forceinline__ void batch_dists(const uint8_t* rows, uint32_t row_st
 #pragma unroll
     for (int cu = 0; cu < CU; cu++) {
       const int c = c0 + cu * G + g;
-      const uint4 x = qlds[c];  // zero beyond the row (q_chunks covers the last c0 block)
+      uint4 x;  // zero beyond the row (q_chunks covers the last c0 block)
+      if constexpr (query_in_regs<G, CU>()) x = q.r[cu];
+      else x = q.lds[c];
       const bool in_row = c < nchunks;
       qacc = D::qchunk(qacc, x);
 #pragma unroll

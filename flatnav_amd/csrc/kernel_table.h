@@ -11,8 +11,8 @@ namespace fnv_dev {
 typedef void (*kernel_fn)(const SearchParams);
 typedef void (*wire_fn)(const WireParams);
 
-// chunks covered per inner iteration = G*CU: 8,16,32,64,128,256 (128 B ... 4 KiB of a row), and 192 for rows that
-// are whole 3 KiB spans (768-d float32 and its multiples: no clamped loads, four vectors in flight -- passes<64,3>)
+// chunks covered per inner iteration = G*CU: 8,16,32,64,128,256 (128 B ... 4 KiB of a row), and 192 for rows of
+// exactly 3 KiB (768-d float32: no clamped loads, four vectors in flight -- passes<64,3>)
 struct KernelCfg {
   int G, CU;
 };
@@ -20,9 +20,11 @@ constexpr KernelCfg kCfgs[] = {{8, 1}, {8, 2}, {8, 4}, {16, 4}, {32, 4}, {64, 4}
 constexpr int kNumCfgs = 7;
 
 // Row configuration for rows of `nchunks` 16-byte chunks: the narrowest one that covers the row in one span; longer
-// rows loop over 256-chunk spans, or over 192-chunk spans when that divides them.
+// rows loop over 256-chunk spans.  Rows of exactly 192 chunks (768-d float32) have their own: every lane loads exactly
+// its three chunks, and the query lives in registers instead of LDS (distance.hpp, query_in_regs).
+inline bool cfg_query_in_regs(int cfg) { return kCfgs[cfg].G == 64 && kCfgs[cfg].CU == 3; }
 inline int pick_row_cfg(uint32_t nchunks) {
-  if (nchunks > 128 && nchunks % 192 == 0) return 6;
+  if (nchunks == 192) return 6;
   for (int c = 0; c < 6; c++)
     if ((uint32_t)(kCfgs[c].G * kCfgs[c].CU) >= nchunks) return c;
   return 5;

@@ -13,7 +13,7 @@ namespace fnv_dev {
 // ---------------------------------------------------------------------------------------------
 template <typename T, int METRIC, int G, int CU, bool FULL>
 __device__ __forceinline__ void scan_rows(const uint8_t* rows, uint32_t stride_rows, uint32_t id_mul, int nchunks,
-                                          const uint4* qlds, uint32_t count, uint32_t j_base, int lane, float& best_d,
+                                          const Query<G, CU>& q, uint32_t count, uint32_t j_base, int lane, float& best_d,
                                           uint32_t& best_j) {
   constexpr int PU = passes<G, CU>();
   constexpr int VPW = WAVE / G;
@@ -29,7 +29,7 @@ __device__ __forceinline__ void scan_rows(const uint8_t* rows, uint32_t stride_r
       sid[pu] = min(j, count - 1) * id_mul;
     }
     const int npass = (int)min((uint32_t)PU, (count - j0 + VPW - 1) / VPW);
-    batch_dists<T, METRIC, G, CU, FULL>(rows, stride_rows, nchunks, qlds, sid, npass, sd, lane);
+    batch_dists<T, METRIC, G, CU, FULL>(rows, stride_rows, nchunks, q, sid, npass, sd, lane);
 #pragma unroll
     for (int pu = 0; pu < PU; pu++) {
       if (sval[pu] && sd[pu] < best_d) {  // strict '<': first minimum wins (Index.h:864)
@@ -89,9 +89,11 @@ __global__ __launch_bounds__(SCAN_WAVES* WAVE) void entry_scan_kernel(const Sear
       const int padded = (int)(qbytes / sizeof(T));
       for (int i = lane; i < padded; i += WAVE) qdst[i] = i < (int)p.dim ? qsrc[i] : T(0);
       wave_sync();
+      Query<G, CU> q;
+      q.from_lds(qlds, lane);
       float best_d = std::numeric_limits<float>::max();
       uint32_t best_j = 0;
-      scan_rows<T, METRIC, G, CU, FULL>(tile, p.scan_tile_stride, 1u, (int)p.nchunks, qlds, rows, t0, lane, best_d, best_j);
+      scan_rows<T, METRIC, G, CU, FULL>(tile, p.scan_tile_stride, 1u, (int)p.nchunks, q, rows, t0, lane, best_d, best_j);
       wave_argmin(best_d, best_j);
       if (lane == 0 && best_d < bd[qq]) {  // later tiles hold larger indices: strict '<' keeps the first minimum
         bd[qq] = best_d;
@@ -119,14 +121,30 @@ __device__ __forceinline__ void reset_visited(uint32_t* vis, uint32_t* ovf_list,
   if ((uint32_t)lane < STASH) ovf_list[OVF_LIST + 2 + lane] = 0u;  // the stash is empty
 }
 
-template <typename T>
-__device__ __forceinline__ void stage_query(uint4* qlds, uint32_t* vis, uint32_t* ovf_list, int qi, bool tagged, int lane) {
+// The query of work item qi: staged in LDS (zero padded to q_chunks), or -- rows of one 192-chunk span, distance.hpp --
+// straight from the caller's array into the lane's registers (no LDS is reserved for it then).
+template <typename T, int G, int CU>
+__device__ __forceinline__ void stage_query(Query<G, CU>& q, uint4* qlds, uint32_t* vis, uint32_t* ovf_list, int qi, bool tagged,
+                                            int lane) {
   ColdArgs c = cold_args();
   const uint32_t dim = c->dim;
   const T* qsrc = reinterpret_cast<const T*>(c->queries) + (uint64_t)qi * dim;
-  T* qdst = reinterpret_cast<T*>(qlds);
-  const int padded = (int)(c->q_chunks * 16u / sizeof(T));
-  for (int i = lane; i < padded; i += WAVE) qdst[i] = i < (int)dim ? qsrc[i] : T(0);
+  q.lds = qlds;
+  if constexpr (query_in_regs<G, CU>()) {
+    constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
+#pragma unroll
+    for (int cu = 0; cu < CU; cu++) {
+      T e[EPC];
+      const int first = (cu * G + lane % G) * EPC;
+#pragma unroll
+      for (int k = 0; k < EPC; k++) e[k] = first + k < (int)dim ? qsrc[first + k] : T(0);
+      q.r[cu] = __builtin_bit_cast(uint4, e);
+    }
+  } else {
+    T* qdst = reinterpret_cast<T*>(qlds);
+    const int padded = (int)(c->q_chunks * 16u / sizeof(T));
+    for (int i = lane; i < padded; i += WAVE) qdst[i] = i < (int)dim ? qsrc[i] : T(0);
+  }
   reset_visited(vis, ovf_list, tagged, lane);
 }
 
@@ -159,7 +177,7 @@ __device__ __forceinline__ int next_query(int lane) {
 
 // Entry point of query qi and its distance: from the batch kernel K0 if it ran, else the in-kernel scan.
 template <typename T, int METRIC, int G, int CU, bool FULL>
-__device__ __forceinline__ uint32_t entry_point(const uint8_t* vectors, uint32_t row_bytes, int nchunks, const uint4* qlds,
+__device__ __forceinline__ uint32_t entry_point(const uint8_t* vectors, uint32_t row_bytes, int nchunks, const Query<G, CU>& q,
                                                 int qi, int lane, float& best_d) {
   ColdArgs c = cold_args();
   const uint32_t* en = c->entry_node;
@@ -170,7 +188,7 @@ __device__ __forceinline__ uint32_t entry_point(const uint8_t* vectors, uint32_t
   best_d = std::numeric_limits<float>::max();
   uint32_t best_j = 0;
   const uint32_t step = c->scan_step;
-  scan_rows<T, METRIC, G, CU, FULL>(vectors, row_bytes, step, nchunks, qlds, c->n_scan, 0u, lane, best_d, best_j);
+  scan_rows<T, METRIC, G, CU, FULL>(vectors, row_bytes, step, nchunks, q, c->n_scan, 0u, lane, best_d, best_j);
   wave_argmin(best_d, best_j);
   return best_j * step;
 }
@@ -179,7 +197,7 @@ __device__ __forceinline__ uint32_t entry_point(const uint8_t* vectors, uint32_t
 // The exact search of ONE query (Index.h:606-707 + :393-408): the reference's two binary heaps moved with
 // libstdc++'s element moves, link-order admissions, result tail.  Called by beam_search_kernel for every query
 // and by beam_search_merged_kernel for the queries in which equal keys met at a decision.
-// Expects the query staged in qlds, the visited table reset, entry / best_d chosen.
+// Expects the query staged (q), the visited table reset, entry / best_d chosen.
 // ---------------------------------------------------------------------------------------------
 struct ExactCtx {
   const uint8_t* vectors;
@@ -189,7 +207,6 @@ struct ExactCtx {
   int cand_slots;  // entries of the candidates heap that live in LDS (0: the whole heap is in the HBM spill area)
   bool tagged;
   VisGeom vg;
-  uint4* qlds;
   unsigned long long* nbr;   // LDS, B + 2 entries, at 16n + 8
   unsigned long long* cand;  // LDS, cand_slots + 1 entries, at 16n + 8 (unused when cand_slots == 0)
   uint32_t* vis;
@@ -200,8 +217,12 @@ struct ExactCtx {
 // `stop` (null: never) = a word another wavefront sets once the same query has been answered (shadow mode, search_params.h):
 // polled once per hop; the search then gives up -- no results written, per-slot state left clean.
 template <typename T, int METRIC, int G, int CU, bool FULL>
-__device__ __forceinline__ void exact_query(const ExactCtx& x, int qi, uint32_t entry, float best_d, int lane,
+__device__ __forceinline__ void exact_query(const ExactCtx& x, const Query<G, CU>& q, int qi, uint32_t entry, float best_d, int lane,
                                             PhaseTimer& ph, const uint32_t* stop = nullptr) {
+  // (the lane index is made opaque here: everything derived from it below -- lane masks, group indices, chunk offsets --
+  // is then computed per call instead of being hoisted to the kernel entry, where the merged-beam kernel, which inlines
+  // this function for its rare re-runs, would have to keep it alive across its own hop loop and spill it to scratch)
+  asm volatile("" : "+v"(lane));
   constexpr int PU = passes<G, CU>();
   const uint8_t* const vectors = x.vectors;
   const uint32_t* const links = x.links;
@@ -209,7 +230,6 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, int qi, uint32_t 
   const int nchunks = x.nchunks, B = x.B, M = x.M, cand_slots = x.cand_slots;
   const bool tagged = x.tagged;
   const VisGeom vg = x.vg;
-  uint4* const qlds = x.qlds;
   uint32_t* const vis = x.vis;
   uint32_t* const stage_ids = x.stage_ids;
   uint32_t* const ovf_list = x.ovf_list;
@@ -317,7 +337,7 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, int qi, uint32_t 
           cid[pu] = stage_ids[min(slot, n - 1)];  // lanes past the end re-read the last real id
         }
         const int npass = min(PU, (n - base + VPW - 1) / VPW);
-        batch_dists<T, METRIC, G, CU, FULL>(vectors, row_bytes, nchunks, qlds, cid, npass, cd, lane);
+        batch_dists<T, METRIC, G, CU, FULL>(vectors, row_bytes, nchunks, q, cid, npass, cd, lane);
         PH_MARK(5);
 
         // ---- admissions in link order (Index.h:667-705).  Superset filter first: max_dist never grows
@@ -368,6 +388,14 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, int qi, uint32_t 
   }
   PH_MARK(2);
 
+  // Shadow mode: a shadow that ran out of candidate-heap room AFTER the merged-beam pass answered the query has nothing to
+  // report either -- the launch-wide status word must not fail a launch whose every query was answered.  (What remains: a
+  // shadow that overflows while the merged-beam pass is still searching records the error even if that pass answers later;
+  // the results it wrote are then overwritten by the right ones, the status stays set -- conservative.)
+  if (err && stop) {
+    const uint32_t answered = __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (rfl((int)answered) != 0) aborted = true;
+  }
   if (aborted) {  // nothing to report; hand the slot's HBM bitmap back clean
     if (ovf) clear_spill_bitmap(bitmap, ovf_list, ovf_glist, tagged, lane);
     __syncthreads();
@@ -463,7 +491,7 @@ __global__ __launch_bounds__(WAVE, waves_per_simd<G>(FNV_MIN_WAVES_PER_SIMD)) vo
   x.cand_slots = (int)p.cand_slots;
   x.tagged = p.vis_tag16 != 0u;
   x.vg = VisGeom{p.vis_nmask, p.vis_rshift, p.vis_rmask, p.vis_mult, p.vis_w};
-  x.qlds = reinterpret_cast<uint4*>(smem + p.off_q);
+  uint4* const qlds = reinterpret_cast<uint4*>(smem + p.off_q);
   x.nbr = reinterpret_cast<unsigned long long*>(smem + p.off_nbr);
   x.cand = reinterpret_cast<unsigned long long*>(smem + p.off_cand);
   x.vis = reinterpret_cast<uint32_t*>(smem + p.off_vis);
@@ -474,14 +502,15 @@ __global__ __launch_bounds__(WAVE, waves_per_simd<G>(FNV_MIN_WAVES_PER_SIMD)) vo
     const int qi = next_query(lane);
     if (qi < 0) break;
     PH_DECL
-    stage_query<T>(x.qlds, x.vis, x.ovf_list, qi, x.tagged, lane);
+    Query<G, CU> q;
+    stage_query<T>(q, qlds, x.vis, x.ovf_list, qi, x.tagged, lane);
     __syncthreads();
     PH_MARK(0);
     // ---- entry-point selection (Index.h:845-870): argmin over nodes 0, s, 2s, ... -----------
     float best_d;
-    const uint32_t entry = entry_point<T, METRIC, G, CU, FULL>(x.vectors, x.row_bytes, x.nchunks, x.qlds, qi, lane, best_d);
+    const uint32_t entry = entry_point<T, METRIC, G, CU, FULL>(x.vectors, x.row_bytes, x.nchunks, q, qi, lane, best_d);
     PH_MARK(1);
-    exact_query<T, METRIC, G, CU, FULL>(x, qi, entry, best_d, lane, ph);
+    exact_query<T, METRIC, G, CU, FULL>(x, q, qi, entry, best_d, lane, ph);
     PH_FLUSH;
   }
 }

@@ -144,12 +144,13 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
     // [B + 2] at 16n + 8 (word -1 = write-only bin): the merge's permutation buffer (register forms) or the beam itself
     // (LDS form), and the neighbours heap of an exact re-run
     unsigned long long* beam = reinterpret_cast<unsigned long long*>(smem + ca->off_nbr);
-    stage_query<T>(qlds, vis, ovf_list, qi, true, lane);
+    Query<G, CU> q;
+    stage_query<T>(q, qlds, vis, ovf_list, qi, true, lane);
     __syncthreads();
     PH_MARK(0);
 
     float best_d;
-    uint32_t entry = entry_point<T, METRIC, G, CU, FULL>(vectors, row_bytes, nchunks, qlds, qi, lane, best_d);
+    uint32_t entry = entry_point<T, METRIC, G, CU, FULL>(vectors, row_bytes, nchunks, q, qi, lane, best_d);
     PH_MARK(1);
     best_d = rfl(best_d);
     entry = (uint32_t)rfl((int)entry);
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
 #pragma unroll
           for (int pu = 0; pu < PU; pu++) cid[pu] = stage_ids[min(base + pu * VPW + v, nn - 1)];
           const int npass = min(PU, (nn - base + VPW - 1) / VPW);
-          batch_dists<T, METRIC, G, CU, FULL>(vectors, row_bytes, nchunks, qlds, cid, npass, cd, lane);
+          batch_dists<T, METRIC, G, CU, FULL>(vectors, row_bytes, nchunks, q, cid, npass, cd, lane);
 #pragma unroll
           for (int pu = 0; pu < PU; pu++) {
             if (pu >= npass) break;
@@ -477,6 +478,13 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
           if (!row_chunk(m0, m0 + lane < M ? links[(uint64_t)(uint32_t)node * (uint32_t)M + m0 + lane] : EMPTY_ID)) break;
     }
 
+    // The query's tail.  The lane index is made opaque once more: what the tail derives from it (result slots, the
+    // re-run's lane masks) is computed here, after the hop loop, instead of being hoisted above it and spilled to scratch
+    // for its whole duration (round 4: the four- and two-chunk forms kept 11-20 such registers in scratch).
+    const int lane_of_hop_loop = lane;
+    {
+    int lane = lane_of_hop_loop;
+    asm volatile("" : "+v"(lane));
     ColdArgs c = cold_args();
     const int K = c->K;
     if (!tie && amb < INF) tie = 1;  // (a) still undecided when the search ended
@@ -530,13 +538,12 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
       x.cand_slots = (int)xa->cand_slots;
       x.tagged = true;
       x.vg = VisGeom{xa->vis_nmask, xa->vis_rshift, xa->vis_rmask, xa->vis_mult, xa->vis_w};
-      x.qlds = reinterpret_cast<uint4*>(smem + xa->off_q);
       x.nbr = reinterpret_cast<unsigned long long*>(smem + xa->off_nbr);
       x.cand = reinterpret_cast<unsigned long long*>(smem + xa->off_cand);
       x.vis = reinterpret_cast<uint32_t*>(smem + xa->off_vis);
       x.stage_ids = reinterpret_cast<uint32_t*>(smem + xa->off_stage_ids);
       x.ovf_list = reinterpret_cast<uint32_t*>(smem + xa->off_ovf);
-      exact_query<T, METRIC, G, CU, FULL>(x, qi, entry, best_d, lane, ph, shadow ? xa->done_flags + qi : nullptr);
+      exact_query<T, METRIC, G, CU, FULL>(x, q, qi, entry, best_d, lane, ph, shadow ? xa->done_flags + qi : nullptr);
       PH_FLUSH;
       continue;
     } else {
@@ -571,6 +578,7 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
       }
     }
     if (ovf) clear_spill_bitmap(bitmap, ovf_list, ovf_glist, true, lane);
+    }
     PH_MARK(7);
     PH_FLUSH;
     __syncthreads();

@@ -86,6 +86,7 @@ struct SearchParams {
   unsigned long long* phase_cycles;  // [16] profiling build only (FNV_PHASE_TIMING), else null
   uint64_t n_nodes;
   uint32_t nq, M, dim, row_bytes, nchunks, q_chunks;
+  uint32_t q_lds_bytes;    // LDS the staged query takes per slot: q_chunks * 16, or 0 when it lives in registers (distance.hpp)
   int K, B;
   uint32_t n_scan, scan_step;
   uint32_t vis_slots, vis_shift, vis_limit;

@@ -146,6 +146,10 @@ __device__ __forceinline__ bool visited_insert_tag16(uint32_t* tab, const VisGeo
     isnew |= won;
     uint32_t to_bitmap = pending & (found ^ 1u) & full;  // both buckets full: the stash, then the HBM bitmap decides (rare)
     if (__ballot(to_bitmap != 0u) != 0ull) visited_stash(ovf_list, to_bitmap, id, isnew);
+#ifdef FNV_EXP_NO_BITMAP  // TIMING EXPERIMENT ONLY (wrong results): ids that overflow the table and the stash count as new,
+    isnew |= to_bitmap;   // nothing goes to HBM -- what do the bitmap's round trips and DRAM operations cost a launch?
+    to_bitmap = 0u;
+#endif
     if (__ballot(to_bitmap != 0u) != 0ull) {
       used_bitmap = true;  // wave-uniform: set for every lane as soon as any lane's id goes to the bitmap
       if (to_bitmap) {
@@ -221,6 +225,10 @@ __device__ __forceinline__ bool visited_insert_tagw(unsigned long long* tab, con
     isnew |= won;
     uint32_t to_bitmap = pending & (found ^ 1u) & full;
     if (__ballot(to_bitmap != 0u) != 0ull) visited_stash(ovf_list, to_bitmap, id, isnew);
+#ifdef FNV_EXP_NO_BITMAP  // TIMING EXPERIMENT ONLY (wrong results): ids that overflow the table and the stash count as new,
+    isnew |= to_bitmap;   // nothing goes to HBM -- what do the bitmap's round trips and DRAM operations cost a launch?
+    to_bitmap = 0u;
+#endif
     if (__ballot(to_bitmap != 0u) != 0ull) {
       used_bitmap = true;  // wave-uniform: set for every lane as soon as any lane's id goes to the bitmap
       if (to_bitmap) {

@@ -98,6 +98,8 @@ __device__ __forceinline__ int prune_ordered(const WireParams& p, uint4* qlds, c
     pos = found + 1;
     if (kept_n >= keep || pos >= C) break;
     stage_vector(qlds, p.vectors, p.row_bytes, (int)p.nchunks, oid[found], lane);
+    Query<G, CU> q;
+    q.from_lds(qlds, lane);
     for (int base = pos; base < C; base += WAVE) {
       const int j = base + lane;
       const bool a = j < C && alive[j] != 0u;
@@ -114,7 +116,7 @@ __device__ __forceinline__ int prune_ordered(const WireParams& p, uint4* qlds, c
 #pragma unroll
         for (int pu = 0; pu < PU; pu++) id[pu] = stage_ids[min(b + pu * VPW + v, n - 1)];
         const int npass = min(PU, (n - b + VPW - 1) / VPW);
-        batch_dists<T, METRIC, G, CU, FULL>(p.vectors, p.row_bytes, (int)p.nchunks, qlds, id, npass, d, lane);
+        batch_dists<T, METRIC, G, CU, FULL>(p.vectors, p.row_bytes, (int)p.nchunks, q, id, npass, d, lane);
 #pragma unroll
         for (int pu = 0; pu < PU; pu++) {
           const int s = b + pu * VPW + v;
@@ -139,13 +141,15 @@ __device__ __forceinline__ void keys_from(const WireParams& p, uint4* qlds, uint
   constexpr int VPW = WAVE / G;
   const int vgrp = lane / G;
   stage_vector(qlds, p.vectors, p.row_bytes, (int)p.nchunks, base, lane);
+  Query<G, CU> q;
+  q.from_lds(qlds, lane);
   for (int b = 0; b < C; b += VPW * PU) {
     uint32_t id[PU];
     float d[PU];
 #pragma unroll
     for (int pu = 0; pu < PU; pu++) id[pu] = cid[min(b + pu * VPW + vgrp, C - 1)];
     const int npass = min(PU, (C - b + VPW - 1) / VPW);
-    batch_dists<T, METRIC, G, CU, FULL>(p.vectors, p.row_bytes, (int)p.nchunks, qlds, id, npass, d, lane);
+    batch_dists<T, METRIC, G, CU, FULL>(p.vectors, p.row_bytes, (int)p.nchunks, q, id, npass, d, lane);
 #pragma unroll
     for (int pu = 0; pu < PU; pu++) {
       const int s = b + pu * VPW + vgrp;

@@ -26,6 +26,7 @@ C_ABI_SYMBOLS = [
     "fnv_index_set_live_nodes", "fnv_index_write_nodes", "fnv_index_write_links", "fnv_index_insert_batch",
     "fnv_index_read_links", "fnv_last_replayed_queries", "fnv_replicate", "fnv_replica_refresh",
     "fnv_search_batch_multi", "fnv_index_view", "fnv_tune", "fnv_last_launch_info", "fnv_gather_ceiling",
+    "fnv_index_adopt",
 ]
 
 _lib = None
@@ -72,6 +73,9 @@ def lib() -> C.CDLL:
     L.fnv_last_replayed_queries.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.fnv_last_launch_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.fnv_index_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    if hasattr(L, "fnv_index_adopt"):  # (older builds of the library, A/B'ed by tools/knob_sweep.py, lack it)
+        L.fnv_index_adopt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_int,
+                                      C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
     L.fnv_replicate.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
     L.fnv_replica_refresh.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     L.fnv_search_batch_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_int,
@@ -160,6 +164,17 @@ class DeviceIndex:
         h = C.c_void_p()
         check(lib().fnv_index_alloc(M, n_nodes, DTYPE_ORD[dtype], METRIC_ORD[metric], dim, device, C.byref(h)))
         return cls(h)
+
+    @classmethod
+    def adopt(cls, buffers, M: int, n_nodes: int, dtype: str, metric: str, dim: int, device: int = 0, keep_alive=None) -> "DeviceIndex":
+        """A handle on device buffers somebody else owns: `buffers` = [(ptr, nbytes)] * 3 as device_buffers() reports them
+        (vectors at the library's row stride, links, labels).  `keep_alive`: whatever must outlive the handle."""
+        h = C.c_void_p()
+        check(lib().fnv_index_adopt(buffers[0][0], buffers[1][0], buffers[2][0], M, n_nodes, DTYPE_ORD[dtype],
+                                    METRIC_ORD[metric], dim, device, C.byref(h)))
+        v = cls(h)
+        v._parent = keep_alive
+        return v
 
     def close(self) -> None:
         if getattr(self, "_h", None):

@@ -93,12 +93,22 @@ int fnv_index_alloc(uint32_t M, uint64_t n_nodes, int data_type, int metric, uin
 
 /* A second handle on the SAME device buffers (vectors / links / labels are shared, not copied) with its own workspace,
  * stream and options (copied from `src` at creation): lets callers keep several searches in flight on one index
- * (fnv_search_batch_device allows one launch in flight per handle).  Measured: back-to-back 10 000-query batches on two
- * handles / two streams run no faster than on one (7.72 M vs 7.65 M queries/s) -- the persistent grids do not overlap
- * usefully -- so this is a concurrency convenience, not a throughput lever.  The view reads the source's live node
+ * (fnv_search_batch_device allows one launch in flight per handle).  Two launches in flight on two handles / two streams
+ * overlap one launch's drain (its last, slowest queries at falling occupancy) with the next one's start: +25-40 %
+ * queries/s on back-to-back 10 000-query batches (round 3: 9.7 -> 11.9 M on 1M x 128 float32, 12.7 -> 19.3 M on the uint8
+ * index; INTEGRATION.md recommends it to callers that always have the next batch ready).  The view reads the source's live node
  * count at every launch (it follows fnv_index_set_live_nodes / fnv_index_insert_batch on the source); the source
  * counts its views and fnv_index_free(source) fails with FNV_ERR_INVALID while any is alive: free views first. */
 int fnv_index_view(fnv_index_t src, fnv_index_t* out);
+
+/* A handle on device buffers that SOMEBODY ELSE owns and keeps alive -- laid out as fnv_index_device_buffers reports
+ * them ([n_nodes][row_bytes] vectors at the library's row stride, see fnv_index_info[2]; [n_nodes][M] uint32 links;
+ * [n_nodes] int32 labels), all on `device`: e.g. buffers that another process shares over HIP IPC, that a collective
+ * filled inside a framework's allocation, or that another build of this library uploaded (tools/knob_sweep.py A/Bs
+ * library builds on one copy of a 32 GB index this way).  The handle has its own workspace, stream and options and never
+ * frees the buffers; there is no reference interface for this (the reference's index lives in one process's heap). */
+int fnv_index_adopt(const void* vectors, const void* links, const void* labels, uint32_t M, uint64_t n_nodes,
+                    int data_type, int metric, uint32_t dim, int device, fnv_index_t* out);
 
 /* Device pointers and byte sizes of the three index buffers: [0]=vectors [1]=links [2]=labels. */
 int fnv_index_device_buffers(fnv_index_t index, void* ptrs[3], uint64_t sizes[3]);
