@@ -57,7 +57,7 @@ CONFIGS = {
     "c3": dict(gen="randn_unit", n=10_000_000, dim=768, metric="angular", ef=200, sweep=[], secondary=[],
                title="C3 as worded: randn rows normalised"),
     "c3-lowrank": dict(gen="lowrank_unit", n=10_000_000, dim=768, metric="angular", ef=0,
-                       sweep=[100, 200, 300, 400, 600, 800, 1000, 1200, 1600], secondary=[200],
+                       sweep=[100, 200, 300, 400, 600, 650, 700, 750, 800, 1000, 1200, 1600], secondary=[200],
                        title="C3 recall-qualified variant (S3 low-rank unit vectors, SURVEY.md 8d)"),
     "c4": dict(gen="glove_like", n=1_183_514, dim=100, metric="angular", ef=0,
                sweep=[50, 64, 80, 100, 110, 120, 140, 170, 200, 400],
@@ -65,10 +65,15 @@ CONFIGS = {
     "c5": dict(gen="randn", n=50_000_000, dim=128, metric="l2", ef=100, sweep=[], secondary=[],
                title="C5 as worded: randn, index replicated per GPU, queries sharded"),
     "c5-lowrank": dict(gen="sift_like", n=50_000_000, dim=128, metric="l2", ef=0,
-                       sweep=[50, 64, 80, 100, 128, 160, 200, 300, 400, 600], secondary=[],
+                       sweep=[50, 64, 72, 76, 80, 100, 128, 160, 200, 300, 400, 600], secondary=[],
                        title="C5 recall-qualified variant (the S1 SIFT stand-in generator at N=50M, SURVEY.md 8d)"),
+    # north_star's bit-exact claim is about integer datasets: the c2 data stored as bytes (1-byte rows, v_dot4 arithmetic)
+    "c2-uint8": dict(gen="sift_like", n=1_000_000, dim=128, metric="l2", ef=0, dtype="uint8",
+                     sweep=[30, 40, 44, 48, 50, 52, 54, 56, 58, 60, 64, 70, 80, 100, 150, 200, 400], secondary=[],
+                     title="SIFT-1M stand-in stored as uint8 (same integer-valued data as c2)"),
 }
-SECONDARY_DEFAULT = {1: "c4,c3-lowrank,c5,c5-lowrank"}  # world size -> configurations after the main one (else: "c5")
+# world size -> configurations after the main one (else: "c5")
+SECONDARY_DEFAULT = {1: "c2-uint8,c4,c3-lowrank,c3,c5,c5-lowrank"}
 
 
 def log(*a):
@@ -267,12 +272,41 @@ def main() -> None:
             out["secondary"].append({"config": name, "value": entry["value"], "unit": entry["unit"],
                                      "ef_search": entry["config"]["ef_search"], "recall_at_10": entry["config"]["recall_at_10"],
                                      "roofline_frac": entry["roofline"]["frac"], "full_entry": "top-level key \"%s\"" % name})
+            log("[bench] " + summary_row(name, entry))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         out["bench_wall_seconds"] = round(time.time() - t_start, 1)
+        # LAST key of the line (round 4): one short row per configuration, so that whatever tail of this (long) line a log
+        # keeps still names every configuration with its ef, recall, queries/s, roofline fraction and CPU baseline.
+        rows = [summary_row(args.config, out)] + [summary_row(n, out[n]) for n in names if isinstance(out.get(n), dict)]
+        out["summary"] = rows
+        for r in rows:
+            log("[bench] " + r)
         print(json.dumps(compact(out), separators=(",", ":")), flush=True)
+
+
+def peer_matrix(world):
+    """hipDeviceCanAccessPeer over the devices the ranks use (BENCH_SHARE_GPU: they all use device 0)."""
+    from flatnav_amd import multigpu
+
+    import torch
+
+    return multigpu.peer_access_matrix(min(world, torch.cuda.device_count()))
+
+
+def summary_row(name, e):
+    """'<config>: ef=.. recall=.. (min over batches ..) <queries/s> frac=.. of 8 TB/s (.. of the gather ceiling) cpu=..'"""
+    if "skipped" in e:
+        return "%s: skipped (%s)" % (name, e["skipped"])
+    c, r = e["config"], e["roofline"]
+    cpu = e.get("cpu_baseline")
+    return ("%s: ef=%d recall@10=%.4f (min over %d batches %.4f) %.4g queries/s kernel %.4g ms frac=%.3f of 8 TB/s (%.2f of its gather "
+            "ceiling) %d/CU cpu=%s"
+            % (name, c["ef_search"], c["recall_at_10"], c["recall_all_timed_batches"]["batches"], c["recall_all_timed_batches"]["min"],
+               e["value"], r["avg_kernel_ms"], r["frac"], r["frac_of_gather_ceiling"], c["launch"]["blocks_per_cu"],
+               "-" if not cpu else "%.4g q/s on %d threads" % (cpu["value"], cpu["cores"])))
 
 
 def compact(obj, top=True):
@@ -300,7 +334,7 @@ def run_config(ctx, args, config, main_line):
     N = args.n or cfg["n"]
     NQ, DIM, M, K = args.nq, cfg["dim"], args.M, args.K
     metric = cfg["metric"]
-    DT = args.dtype
+    DT = cfg.get("dtype", args.dtype)
     if DT == "uint8" and cfg["gen"] != "sift_like":
         raise SystemExit("--dtype uint8 needs the integer-valued c2 data")
     ESIZE = 4 if DT == "float32" else 1
@@ -336,12 +370,14 @@ def run_config(ctx, args, config, main_line):
         dev = hip.DeviceIndex(ctypes.c_void_p(index.device_handle()), owned=False)  # the handle belongs to `index`
     else:
         dev = hip.DeviceIndex.alloc(M, N, DT, metric, DIM, device=local_rank)
+    bcast = None
     if world > 1:
         from flatnav_amd import multigpu
 
         t0 = time.time()
-        multigpu.replicate_index(dev, local_rank, src=0)  # one RCCL broadcast per buffer over xGMI, at load only
-        log("[rank %d] index broadcast %.2fs" % (rank, time.time() - t0))
+        bcast = multigpu.replicate_index(dev, local_rank, src=0)  # RCCL broadcasts over xGMI, <= 2 GB pieces, at load only
+        log("[rank %d] index broadcast %.2fs: %s" % (rank, time.time() - t0, ", ".join(
+            "%s %.2f GB in %d pieces %.1f GB/s" % (b["buffer"], b["bytes"] / 1e9, b["pieces"], b["GBps"] or 0) for b in bcast)))
     for o in args.opt:
         k, v = o.split("=")
         dev.set_option(k, int(v))
@@ -365,20 +401,27 @@ def run_config(ctx, args, config, main_line):
 
     # ---- exact ground truth for recall@10: brute force on the GPU against the index's own HBM vector table,
     #      all NQ queries of this rank's first batch (rank 0 decides ef; every rank needs only ef) ----------------
-    gt = None
+    #      Round 4: EVERY batch the timed region searches has its ground truth, the rule has to hold on each of them.
+    gts = None
     if rank == 0:
         t0 = time.time()
-        gt = exact_topk(torch, dev, dq[0], K, N, DIM, DT, metric)
-        log("[rank 0] exact ground truth for %d queries: %.1fs" % (NQ, time.time() - t0))
+        gts = [exact_topk(torch, dev, dq[b], K, N, DIM, DT, metric) for b in range(nb)]
+        log("[rank 0] exact ground truth for %d x %d queries: %.1fs" % (nb, NQ, time.time() - t0))
 
-    def recall_at(ef):
-        dev.search_device(dq[0].data_ptr(), NQ, K, ef, 100, d_dist.data_ptr(), d_lab.data_ptr(), stream=stream.cuda_stream)
+    def recall_at(ef, b=0):
+        dev.search_device(dq[b].data_ptr(), NQ, K, ef, 100, d_dist.data_ptr(), d_lab.data_ptr(), stream=stream.cuda_stream)
         torch.cuda.synchronize()
         dev.status()
-        return float((d_lab.long().unsqueeze(2) == gt.unsqueeze(1)).any(dim=2).float().mean().item())
+        return float((d_lab.long().unsqueeze(2) == gts[b].unsqueeze(1)).any(dim=2).float().mean().item())
+
+    def recall_all(ef):
+        """recall@10 of every batch of the timed region -> (min, mean, list)."""
+        r = [recall_at(ef, b) for b in range(nb)]
+        return min(r), float(np.mean(r)), r
 
     # ---- ef_search: fixed by the configuration, or the metric's rule (rank 0 decides) ----------------------------
     sweep_rec = {}
+    sweep_min = {}  # ef -> lowest recall over the batches, for the efs whose batch 0 passed
     EF = cfg["ef"] if args.ef < 0 else args.ef
     sweep = [int(x) for x in args.ef_sweep.split(",")] if args.ef_sweep else cfg["sweep"]
     if EF == 0:
@@ -387,6 +430,9 @@ def run_config(ctx, args, config, main_line):
             if rank == 0:
                 sweep_rec[ef] = round(recall_at(ef), 4)
                 ok = sweep_rec[ef] >= 0.95
+                if ok:  # the rule holds on batch 0: it has to hold on every batch that will be timed
+                    sweep_min[ef] = round(recall_all(ef)[0], 4)
+                    ok = sweep_min[ef] >= 0.95
             if dist is not None:
                 flag = torch.tensor([1 if ok else 0], device=dev_t)
                 dist.broadcast(flag, src=0)
@@ -396,7 +442,7 @@ def run_config(ctx, args, config, main_line):
                 break
         if EF == 0:
             EF = max(sweep)
-        log("[rank %d] ef sweep %s -> ef_search=%d" % (rank, sweep_rec, EF))
+        log("[rank %d] ef sweep %s (lowest batch: %s) -> ef_search=%d" % (rank, sweep_rec, sweep_min, EF))
 
     def barrier():
         if dist is not None:
@@ -404,6 +450,7 @@ def run_config(ctx, args, config, main_line):
         torch.cuda.synchronize()
 
     tuned = {}
+    per_rank = []  # seconds each rank measured for the most recent timed region (N > 1)
 
     def run(ef, steps, warmup, min_seconds=0.0):
         """Times `steps` launches (batch i mod nb each); returns (elapsed, kernel_ms list, steps done)."""
@@ -441,10 +488,13 @@ def run_config(ctx, args, config, main_line):
         barrier()
         elapsed = time.perf_counter() - t0
         dev.status()
+        per_rank.clear()
         if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            mine = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            per_rank.extend(float(x.item()) for x in every)  # each rank's own clock around the same barriers
+            elapsed = max(per_rank)
         return elapsed, [a.elapsed_time(b) for a, b in evs], i, explored
 
     step_nodes = max(1, N // 100)
@@ -474,9 +524,14 @@ def run_config(ctx, args, config, main_line):
                     nh=nh_mean, kernel_ms=avg_kernel_s * 1e3, achieved=byts / avg_kernel_s / 1e9, explored=explored)
 
     main_m = measure(EF, args.steps, args.warmup)
+    main_per_rank = list(per_rank)
     out = None
     if rank == 0:
-        recall = recall_at(EF)
+        rec_min, rec_mean, rec_list = recall_all(EF)
+        recall = rec_list[0]
+        dev.search_device(dq[(args.steps - 1) % nb].data_ptr(), NQ, K, EF, 100, d_dist.data_ptr(), d_lab.data_ptr(),
+                          d_cnt.data_ptr(), d_nd.data_ptr(), d_nh.data_ptr(), stream=stream.cuda_stream)  # (geometry of a timed launch)
+        torch.cuda.synchronize()
         geom = dev.launch_geometry()
         info = dev.launch_info()
         replay = dev.replayed_queries()
@@ -529,7 +584,7 @@ def run_config(ctx, args, config, main_line):
                                  "above times exactly --steps launches)" % (args.sustain_seconds, nb)}
         for ef2 in cfg["secondary"]:
             m2 = measure(ef2, max(5, min(args.steps, 20)), min(5, args.warmup))
-            rec2 = recall_at(ef2) if rank == 0 else None
+            rec2 = recall_at(ef2) if rank == 0 else None  # (batch 0: a fixed-ef line, not a recall-rule point)
             secondary.append({"ef_search": ef2, "value": m2["qps"], "unit": "queries/s",
                               "recall_at_10": None if rec2 is None else round(rec2, 4),
                               "ms_per_step": m2["elapsed"] / m2["steps"] * 1e3, "steps": m2["steps"],
@@ -560,13 +615,23 @@ def run_config(ctx, args, config, main_line):
                                args.efc, EF, K, NQ),
                 "recall_at_10": round(recall, 4),
                 "recall_queries": NQ,
+                "recall_all_timed_batches": {"min": round(rec_min, 4), "mean": round(rec_mean, 4), "batches": nb,
+                                             "queries_per_batch": NQ},
                 "ef_search": EF,
                 "ef_selection": ("fixed (configuration / --ef)" if not sweep_rec else
-                                 "smallest ef of the sweep with recall@10 >= 0.95 on all %d queries of batch 0 "
-                                 "(SURVEY.md 8d); recalls: %s" % (NQ, sweep_rec)),
+                                 "smallest ef of the sweep with recall@10 >= 0.95 on all %d queries of batch 0 AND of every "
+                                 "other timed batch (SURVEY.md 8d); batch-0 recalls: %s; lowest batch at the efs that "
+                                 "passed on batch 0: %s" % (NQ, sweep_rec, sweep_min)),
                 "data_note": data.note,
                 "index_build": build_note,
                 "parallelism": "index replicated x%d, queries sharded" % world,
+                "multi_gpu": None if world == 1 else {
+                    "per_rank_queries_per_s": [NQ * args.steps / t for t in main_per_rank],
+                    "per_rank_seconds": main_per_rank,
+                    "index_broadcast": bcast,
+                    "peer_access": peer_matrix(world),
+                    "note": "value = all ranks' queries / the slowest rank's seconds; the index went out from rank 0 in "
+                            "<= 2 GB RCCL broadcasts (per buffer: bytes, pieces, seconds, GB/s as rank 0 saw them)"},
                 "mean_dist_evals_per_query": main_m["nd"],
                 "mean_hops_per_query": main_m["nh"],
                 "launch": geom,
@@ -621,7 +686,7 @@ def run_config(ctx, args, config, main_line):
                 out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"].split("; host:")[0]
     # ---- give everything back before the next configuration ----------------------------------------------------------
     dev.close()
-    del dev, index, dq, d_dist, d_lab, d_cnt, d_nd, d_nh, gt, data, Q_all, Q_rank
+    del dev, index, dq, d_dist, d_lab, d_cnt, d_nd, d_nh, gts, data, Q_all, Q_rank
     gc.collect()
     torch.cuda.empty_cache()
     return out

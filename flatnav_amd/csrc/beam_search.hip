@@ -277,6 +277,12 @@ struct fnv_index_s : IndexOptions {
   // staging for the host-buffer entry point
   void* h_pin = nullptr;  // 1 MB of pinned host memory: staging of small host-buffer searches
   PinnedCall pin;
+  // Large host-buffer searches (round 4, search_host_pipelined): chunks of the batch alternate between this handle and an
+  // internal view of it (second workspace + stream), staged through pinned memory
+  fnv_index_s* pipe_view = nullptr;
+  void* h_pipe = nullptr;  // pinned: [queries of the batch][per-chunk result slabs]
+  size_t h_pipe_bytes = 0;
+  std::vector<hipEvent_t> pipe_ev;  // one per chunk: its results have landed in h_pipe
   void* d_q = nullptr;
   size_t d_q_bytes = 0;
   void* d_out = nullptr;
@@ -559,6 +565,11 @@ int fnv_index_info(fnv_index_t ix, uint64_t info[8]) {
 
 int fnv_index_free(fnv_index_t ix) {
   if (!ix) return FNV_OK;
+  if (ix->pipe_view) {  // the internal view of the pipelined host path goes first (it counts as a view of this handle)
+    fnv_index_s* v = ix->pipe_view;
+    ix->pipe_view = nullptr;
+    (void)fnv_index_free(v);
+  }
   if (ix->n_views.load() > 0)
     return fail(FNV_ERR_INVALID, "fnv_index_free: the index still has live views (fnv_index_view) on its buffers; free them first");
   DeviceScope scope(ix->device);
@@ -569,6 +580,8 @@ int fnv_index_free(fnv_index_t ix) {
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (ix->h_pin) (void)hipHostFree(ix->h_pin);
+  if (ix->h_pipe) (void)hipHostFree(ix->h_pipe);
+  for (hipEvent_t e : ix->pipe_ev) (void)hipEventDestroy(e);
   if (ix->ev0) (void)hipEventDestroy(ix->ev0);
   if (ix->ev1) (void)hipEventDestroy(ix->ev1);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -1193,12 +1206,166 @@ static int check_search_args(fnv_index_t ix, const void* queries, uint64_t nq, i
   return FNV_OK;
 }
 
+// Large host-buffer searches (SURVEY.md 8d defines the metric on the batched call INCLUDING the H2D of the queries and
+// the D2H of the results; reference: bindings.cpp:161-228 hands host arrays in and out).  Round 3 sent the whole batch
+// through one pageable hipMemcpyAsync (which blocks its caller while the runtime stages it), one launch and five pageable
+// copies back: 0.75-0.92 of the device-resident rate.  Now the batch is cut into chunks -- 512, 1024, 2048, then 4096
+// queries -- and each chunk is staged by the CPU into pinned memory, copied, searched and copied back on its own, chunks
+// alternating between this handle's stream and an internal view's (two launches in flight: the next chunk's queries start
+// on the slots the previous chunk's stragglers leave idle), so the GPU starts after the first 512 queries have been staged
+// (~30 us) and staging, copies and searches of later chunks overlap; results are scattered to the caller's arrays as each
+// chunk's event completes.  Same bytes as one launch: queries are independent, a chunk is a batch.
+// When the tuned choice for this beam width says equal keys make last-round re-runs expensive (a tail variant), the
+// last chunk is kept small and searched by the exact two-heap kernel alone.
+static int search_host_pipelined(fnv_index_t ix, const void* queries, uint64_t nq, int K, int ef_search, int num_initializations,
+                                 float* out_dist, int32_t* out_labels, int32_t* out_count, uint64_t* out_ndist,
+                                 uint64_t* out_nhops) {
+  ON_DEVICE(ix->device);
+  const size_t qrow = (size_t)ix->dim * dtype_size(ix->dtype);
+  const size_t orow = (size_t)K * 8 + 4 + 8 + 8;  // per query: K distances, K labels, count, n_dist, n_hops
+  auto slab_bytes = [&](uint64_t n) { return ((size_t)n * orow + 8 + 63) & ~(size_t)63; };  // (+8: the counters start 8-byte aligned)
+  // ---- the variant every chunk runs: never an exploratory one inside a caller's search
+  const int B = std::max(ef_search, K);
+  int chunk_variant = 1, tuned = -1;
+  {
+    std::lock_guard<std::mutex> lock(ix->mu);
+    for (int key : {2 * B + 1, 2 * B}) {
+      auto it = ix->tuner.find(key);
+      if (it == ix->tuner.end() || it->second.samples[0] == 0 || it->second.samples[1] == 0) continue;
+      const fnv_index_s::Tuner& t = it->second;
+      int best = 0;
+      for (int v = 1; v < kNumVariants; v++)
+        if (t.samples[v] > 0 && t.best[v] < t.best[best]) best = v;
+      tuned = best;
+      chunk_variant = best == 0 ? 0 : 1;
+      break;
+    }
+    if (ix->sorted_variant >= 0) chunk_variant = ix->sorted_variant == 0 ? 0 : 1, tuned = (int)ix->sorted_variant;
+  }
+  const bool exact_last = tuned >= 2;
+  // ---- chunk plan
+  std::vector<uint64_t> lo, cnt;
+  {
+    uint64_t done = 0, size = 512;
+    while (done < nq) {
+      uint64_t n = std::min<uint64_t>(size, nq - done);
+      if (exact_last && nq - done > 1024 && nq - done - n < 1024) n = nq - done - 1024;  // leave a last chunk of 1024
+      lo.push_back(done);
+      cnt.push_back(n);
+      done += n;
+      if (size < 4096) size *= 2;
+    }
+  }
+  const size_t nchunk = lo.size();
+  size_t slabs = 0;
+  std::vector<size_t> slab_off(nchunk);
+  for (size_t c = 0; c < nchunk; c++) {
+    slab_off[c] = slabs;
+    slabs += slab_bytes(cnt[c]);
+  }
+  const size_t qbytes = ((size_t)nq * qrow + 63) & ~(size_t)63;
+  {
+    std::lock_guard<std::mutex> lock(ix->mu);
+    int rc = grow(&ix->d_q, &ix->d_q_bytes, qbytes);
+    if (!rc) rc = grow(&ix->d_out, &ix->d_out_bytes, slabs);
+    if (rc) return rc;
+    if (qbytes + slabs > ix->h_pipe_bytes) {
+      if (ix->h_pipe) HIP_TRY(hipHostFree(ix->h_pipe));
+      ix->h_pipe = nullptr;
+      ix->h_pipe_bytes = 0;
+      HIP_TRY(hipHostMalloc(&ix->h_pipe, qbytes + slabs, hipHostMallocDefault));
+      ix->h_pipe_bytes = qbytes + slabs;
+    }
+    while (ix->pipe_ev.size() < nchunk) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      ix->pipe_ev.push_back(e);
+    }
+  }
+  if (!ix->pipe_view) {
+    fnv_index_t v = nullptr;
+    int rc = fnv_index_view(ix, &v);
+    if (rc) return rc;
+    ix->pipe_view = v;
+  }
+  fnv_index_s* view = ix->pipe_view;
+  {  // the view answers exactly like its source: same options, same measured layouts
+    std::lock_guard<std::mutex> l1(ix->mu);
+    std::lock_guard<std::mutex> l2(view->mu);
+    if (view->options_version != ix->options_version || view->layouts.size() != ix->layouts.size()) {
+      static_cast<IndexOptions&>(*view) = static_cast<const IndexOptions&>(*ix);
+      view->layouts = ix->layouts;
+      view->options_version = ix->options_version;
+      view->plan.valid = false;
+    }
+  }
+  uint8_t* hq = (uint8_t*)ix->h_pipe;
+  uint8_t* ho = hq + qbytes;
+  uint8_t* dq = (uint8_t*)ix->d_q;
+  uint8_t* dout = (uint8_t*)ix->d_out;
+  fnv_index_s* handles[2] = {ix, view};
+  bool first = true;
+  for (size_t c = 0; c < nchunk; c++) {
+    fnv_index_s* h = handles[c & 1];
+    const uint64_t n = cnt[c];
+    memcpy(hq + lo[c] * qrow, (const uint8_t*)queries + lo[c] * qrow, n * qrow);
+    HIP_TRY(hipMemcpyAsync(dq + lo[c] * qrow, hq + lo[c] * qrow, n * qrow, hipMemcpyHostToDevice, h->stream));
+    uint8_t* o = dout + slab_off[c];
+    float* od = (float*)o;
+    int32_t* ol = (int32_t*)(o + n * K * 4);
+    int32_t* oc = (int32_t*)(o + n * K * 8);
+    uint64_t* ond = (uint64_t*)(o + ((n * K * 8 + n * 4 + 7) & ~(size_t)7));
+    uint64_t* onh = ond + n;
+    const int variant = (exact_last && c + 1 == nchunk && nchunk > 1) ? 0 : chunk_variant;
+    int rc = search_device_impl(h, dq + lo[c] * qrow, n, K, ef_search, num_initializations, od, ol, oc, ond, onh, h->stream,
+                                ix->output_node_ids != 0, variant);
+    if (rc) {
+      for (fnv_index_s* hh : handles) (void)hipStreamSynchronize(hh->stream);
+      return rc;
+    }
+    if (first) ix->t_enqueue_ns = now_ns();
+    first = false;
+    HIP_TRY(hipMemcpyAsync(ho + slab_off[c], o, (size_t)((uint8_t*)(onh + n) - o), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipEventRecord(ix->pipe_ev[c], h->stream));
+  }
+  int status = ST_OK;
+  for (size_t c = 0; c < nchunk; c++) {
+    HIP_TRY(hipEventSynchronize(ix->pipe_ev[c]));
+    const uint64_t n = cnt[c];
+    const uint8_t* o = ho + slab_off[c];
+    memcpy(out_dist + lo[c] * K, o, n * K * 4);
+    memcpy(out_labels + lo[c] * K, o + n * K * 4, n * K * 4);
+    if (out_count) memcpy(out_count + lo[c], o + n * K * 8, n * 4);
+    const uint8_t* ond = o + ((n * K * 8 + n * 4 + 7) & ~(size_t)7);
+    if (out_ndist) memcpy(out_ndist + lo[c], ond, n * 8);
+    if (out_nhops) memcpy(out_nhops + lo[c], ond + n * 8, n * 8);
+  }
+  ix->t_complete_ns = now_ns();
+  for (fnv_index_s* h : handles) {  // the sticky status word of either workspace
+    int32_t st = 0;
+    HIP_TRY(hipMemcpy(&st, h->d_dispenser + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (st != ST_OK) status = st;
+  }
+  if (status == ST_CAND_OVERFLOW)
+    return fail(FNV_ERR_CAPACITY, "candidate heap overflowed its HBM spill area; raise the spill_entries option");
+  return FNV_OK;
+}
+
 int fnv_search_batch(fnv_index_t ix, const void* queries, uint64_t nq, int K, int ef_search, int num_initializations,
                      float* out_dist, int32_t* out_labels, int32_t* out_count, uint64_t* out_ndist,
                      uint64_t* out_nhops) {
   int rc = check_search_args(ix, queries, nq, K, ef_search, num_initializations, out_dist, out_labels);
   if (rc || nq == 0) return rc;
   std::lock_guard<std::mutex> host_lock(ix->host_mu);  // concurrent callers share one staging area: serialise
+  {
+    // batches that do not fit the 1 MB pinned buffer of the small-batch path go through the chunked pipeline
+    const size_t qbytes = (size_t)nq * ix->dim * dtype_size(ix->dtype);
+    const size_t obytes = (size_t)nq * ((size_t)K * 8 + 4 + 8 + 8) + 64;
+    const bool small = ((qbytes + 63) & ~(size_t)63) + ((obytes + 63) & ~(size_t)63) + 128 <= (1u << 20);
+    if (!small && nq >= 1024 && !ix->parent)  // (a view has no view of its own: it takes the plain path)
+      return search_host_pipelined(ix, queries, nq, K, ef_search, num_initializations, out_dist, out_labels, out_count, out_ndist,
+                                   out_nhops);
+  }
   rc = search_host_enqueue(ix, queries, nq, K, ef_search, num_initializations, out_dist, out_labels, out_count,
                            out_ndist, out_nhops);
   if (rc) return rc;

@@ -73,7 +73,7 @@ def lib() -> C.CDLL:
     L.fnv_last_replayed_queries.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.fnv_last_launch_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.fnv_index_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
-    if hasattr(L, "fnv_index_adopt"):  # (older builds of the library, A/B'ed by tools/knob_sweep.py, lack it)
+    if hasattr(L, "fnv_index_adopt"):  # (older builds of the library, A/B'ed by tools/dev/knob_sweep.py, lack it)
         L.fnv_index_adopt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_int,
                                       C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
     L.fnv_replicate.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]

@@ -30,18 +30,43 @@ class _DevView:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
-def broadcast_buffers(tensors: List["torch.Tensor"], src: int = 0, group=None) -> None:
-    """One broadcast per buffer (vectors, links, labels).  Works on CUDA tensors (RCCL) and on CPU
-    tensors (gloo, used by the tests)."""
+BROADCAST_PIECE_BYTES = 2 << 30  # one collective moves at most this much (a 32 GB vector table goes out as 16 pieces)
+
+
+def broadcast_buffers(tensors: List["torch.Tensor"], src: int = 0, group=None, piece_bytes: int = BROADCAST_PIECE_BYTES,
+                      sync=None) -> List[dict]:
+    """Broadcast every buffer (vectors, links, labels) from `src`, in pieces of at most `piece_bytes`: one RCCL broadcast
+    of 3.2e10 bytes is a single ring transfer nobody can watch, and its element count overflows a 32-bit int in more than
+    one place of the stack; pieces cost nothing (each is still >= 1 GB: bandwidth-bound over xGMI) and give a progress and
+    bandwidth report.  Works on CUDA tensors (RCCL) and on CPU tensors (gloo, used by the tests).  `sync`: a callable that
+    waits for the device (bandwidth is measured per buffer when given).  Returns [{bytes, pieces, seconds, GBps}] per buffer."""
+    import time
+
     import torch.distributed as dist
 
+    stats = []
     for t in tensors:
-        dist.broadcast(t, src=src, group=group)
+        flat = t.reshape(-1)
+        per = max(1, piece_bytes // max(1, flat.element_size()))
+        pieces = 0
+        if sync:
+            sync()
+        t0 = time.perf_counter()
+        for lo in range(0, flat.numel(), per):
+            dist.broadcast(flat[lo:lo + per], src=src, group=group)
+            pieces += 1
+        if sync:
+            sync()
+        dt = time.perf_counter() - t0
+        nbytes = flat.numel() * flat.element_size()
+        stats.append({"bytes": nbytes, "pieces": pieces, "seconds": dt, "GBps": nbytes / dt / 1e9 if dt > 0 else None})
+    return stats
 
 
-def replicate_index(dev, device: int, src: int = 0, group=None) -> None:
+def replicate_index(dev, device: int, src: int = 0, group=None, piece_bytes: int = BROADCAST_PIECE_BYTES) -> List[dict]:
     """Fill this rank's DeviceIndex (flatnav_amd.hip.DeviceIndex: uploaded on `src`, alloc()'ed elsewhere)
-    from rank `src` with RCCL broadcasts of its three HBM buffers."""
+    from rank `src` with RCCL broadcasts of its three HBM buffers (in <= 2 GB pieces).  Returns broadcast_buffers' report,
+    labelled vectors / links / labels."""
     import torch
 
     # broadcast the LIVE rows only: a device-built source may hold room for more nodes than it has, and the
@@ -52,8 +77,17 @@ def replicate_index(dev, device: int, src: int = 0, group=None) -> None:
         if want > nbytes:
             raise RuntimeError("device buffer smaller than its live rows")
         views.append(torch.as_tensor(_DevView(ptr, want), device="cuda:%d" % device))
-    broadcast_buffers(views, src=src, group=group)
-    torch.cuda.synchronize(device)
+    stats = broadcast_buffers(views, src=src, group=group, piece_bytes=piece_bytes, sync=lambda: torch.cuda.synchronize(device))
+    for name, st in zip(("vectors", "links", "labels"), stats):
+        st["buffer"] = name
+    return stats
+
+
+def peer_access_matrix(n_devices: int) -> List[List[bool]]:
+    """hipDeviceCanAccessPeer for every ordered pair of the first n devices (diagonal: True)."""
+    import torch
+
+    return [[i == j or bool(torch.cuda.can_device_access_peer(i, j)) for j in range(n_devices)] for i in range(n_devices)]
 
 
 def gather_rows(local, num_queries: int, group=None):

@@ -8,6 +8,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# Lines the tests want in the run's terminal summary -- it is printed under -q as well, so the driver's log tail says which
+# sizes ran ("10M x 768 / 50M x 128 FULL SIZE") and which id-equality fractions were measured.
+SUMMARY_LINES = []
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if SUMMARY_LINES:
+        terminalreporter.write_sep("-", "flatnav_amd: sizes and measured parity fractions")
+        for line in SUMMARY_LINES:
+            terminalreporter.write_line(line)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running CPU test")

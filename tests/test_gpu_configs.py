@@ -17,27 +17,31 @@ from flatnav_amd import datasets as ds
 pytestmark = pytest.mark.gpu
 ID_BAR = 0.999
 # GPU vs the same graph searched with the reference's own compiled distance kernel (oracle/_ref: AVX-512 lanes, -ffast-math --
-# a third summation order, neither the oracle's nor the GPU's).  On 768-d random unit vectors every distance lies within a few
-# per cent of 1, last-bit differences reorder near ties, and the oracle's graph is built by 8 racing threads (another graph
-# every run): 1-3 of 1000 queries differ from run to run.  The parity claim is the bar above (GPU vs oracle); this one
-# bounds the sensitivity to the summation order.
-REF_ORDER_BAR = 0.995
+# a third summation order, neither the oracle's nor the GPU's).  Round 4: every oracle graph of the GPU suite is built by ONE
+# thread, so inputs -- and the fractions printed below -- are the same run after run.  On 768-d random unit vectors every
+# distance lies within a few per cent of 1 and last-bit differences between summation orders reorder near ties in 1-3 of 1000
+# queries: that data set keeps its own bar (REF_ORDER_BAR_RANDN_768), every other shape meets the survey's 99.9 %.  The parity
+# claim proper is ID_BAR (GPU vs oracle); these bound the sensitivity to the summation order.
+REF_ORDER_BAR = 0.999
+REF_ORDER_BAR_RANDN_768 = 0.995
+# what the fixture-scoped summary prints at the end of the run (conftest.pytest_terminal_summary): sizes and id fractions
+from conftest import SUMMARY_LINES  # noqa: E402
 
 
 def _fullsize() -> bool:
     """Run the property tests at 10M x 768 / 50M x 128?  FNV_FULLSIZE=0/1 decides; unset: yes when the GPU has >= 200 GB
-    and the host >= 160 GB of memory (node store 32 GB + the oracle's copy + staging)."""
+    and the host >= 160 GB of memory (node store 32 GB + the oracle's copy + staging).  A probe that RAISES fails the test
+    (round 4): a box that qualifies must never silently run the reduced size."""
     env = os.environ.get("FNV_FULLSIZE")
     if env is not None:
         return env == "1"
-    try:
-        import psutil
-        import torch
+    import psutil
+    import torch
 
-        return (torch.cuda.get_device_properties(0).total_memory >= 200 * 2 ** 30
-                and psutil.virtual_memory().available >= 160 * 2 ** 30)
-    except Exception:
-        return False
+    gpu, host = torch.cuda.get_device_properties(0).total_memory, psutil.virtual_memory().available
+    SUMMARY_LINES.append("full-size probe: GPU %.0f GB (>= 200 needed), host memory available %.0f GB (>= 160 needed)"
+                         % (gpu / 2 ** 30, host / 2 ** 30))
+    return gpu >= 200 * 2 ** 30 and host >= 160 * 2 ** 30
 
 
 @pytest.fixture(scope="module")
@@ -55,12 +59,12 @@ def _oracle_index(oracle_mod, metric, X, M, efc):
     key = (metric, X.shape, M, efc, float(X[0, 0]), float(X[-1, -1]))
     if key not in _CACHE:
         ix = oracle_mod.OracleIndex.create(metric, X.shape[1], X.shape[0], M, "float32")
-        ix.add(X, efc, threads=8)  # multi-threaded oracle build: any valid graph will do for SEARCH parity
+        ix.add(X, efc)  # one thread: the same graph in every run
         _CACHE[key] = ix
     return _CACHE[key]
 
 
-def _float_parity(oracle_mod, hipmod, ix, Q, K, ef, kernels=("default", "two_heaps")):
+def _float_parity(oracle_mod, hipmod, ix, Q, K, ef, kernels=("default", "two_heaps"), ref_bar=REF_ORDER_BAR):
     dev = hipmod.DeviceIndex.upload(ix.blob(), ix.node_size, ix.data_size, ix.M, ix.cur_nodes, ix.dtype, ix.metric, ix.dim)
     ix.use_reference_distance(False)
     od, ol, ost = ix.search(Q, K, ef, threads=8, stats=True)
@@ -72,6 +76,8 @@ def _float_parity(oracle_mod, hipmod, ix, Q, K, ef, kernels=("default", "two_hea
         gd, gl, gst = dev.search(Q, K, ef, stats=True)
         same = (ol == gl).all(axis=1)
         print("%s kernel, ef=%d: ids identical to the oracle on %.2f%% of %d queries" % (kern, ef, 100 * same.mean(), len(Q)))
+        SUMMARY_LINES.append("%s %dx%d ef=%d %s kernel: ids == oracle on %.2f%% of %d queries"
+                             % (ix.metric, ix.cur_nodes, ix.dim, ef, kern, 100 * same.mean(), len(Q)))
         assert same.mean() >= ID_BAR, "%s: ids identical on only %.4f of the queries" % (kern, same.mean())
         assert np.allclose(od[same], gd[same], rtol=1e-5, atol=1e-6)
         # same path through the graph <=> same counters
@@ -80,7 +86,9 @@ def _float_parity(oracle_mod, hipmod, ix, Q, K, ef, kernels=("default", "two_hea
         if have_ref:
             same_r = (rl == gl).all(axis=1)
             print("%s kernel vs the reference's distance kernel: ids identical on %.2f%%" % (kern, 100 * same_r.mean()))
-            assert same_r.mean() >= REF_ORDER_BAR, "%s vs reference distance kernel: %.4f" % (kern, same_r.mean())
+            SUMMARY_LINES.append("%s %dx%d ef=%d %s kernel: ids == oracle on the reference's AVX-512 distances on %.2f%%"
+                                 % (ix.metric, ix.cur_nodes, ix.dim, ef, kern, 100 * same_r.mean()))
+            assert same_r.mean() >= ref_bar, "%s vs reference distance kernel: %.4f" % (kern, same_r.mean())
             assert np.allclose(rd[same_r], gd[same_r], rtol=1e-5, atol=1e-6)
     return dev
 
@@ -93,7 +101,7 @@ def test_c3_shape_768d_float_inner_product_ef200(oracle_mod, hipmod, kind):
     else:
         X, Q = ds.lowrank_normalized(N, NQ, dim=768, rank=32, seed=7712)
     ix = _oracle_index(oracle_mod, "angular", X, 32, 100)
-    dev = _float_parity(oracle_mod, hipmod, ix, Q, 10, 200)
+    dev = _float_parity(oracle_mod, hipmod, ix, Q, 10, 200, ref_bar=REF_ORDER_BAR_RANDN_768 if kind == "randn_unit" else REF_ORDER_BAR)
     dev.set_option("sorted_beam", 2)
     dev.search(Q, 10, 200)
     g = dev.launch_geometry()
@@ -129,6 +137,8 @@ def test_fullsize_properties(oracle_mod, config, n_small, n_full):
     full = _fullsize()
     N = n_full if full else n_small
     print("%s at N = %d (%s)" % (config, N, "FULL SIZE" if full else "reduced: not enough GPU / host memory, or FNV_FULLSIZE=0"))
+    SUMMARY_LINES.append("test_fullsize_properties[%s]: N = %d x %d -- %s" % (config, N, 768 if config == "c3-lowrank" else 128,
+                                                                            "FULL SIZE" if full else "REDUCED (box too small or FNV_FULLSIZE=0)"))
     dim, metric, ef = (768, "angular", 200) if config == "c3-lowrank" else (128, "l2", 100)
     NQ, K, M = 2000, 10, 32
     g = torch.Generator(device="cuda")
@@ -159,4 +169,5 @@ def test_fullsize_properties(oracle_mod, config, n_small, n_full):
     od, ol = o.search(Q[:1000], K, ef, threads=min(16, os.cpu_count() or 1))
     same = (ol == l[:1000]).all(axis=1)
     print("%s N=%d: ids identical to the oracle on %.2f%% of 1000 queries" % (config, N, 100 * same.mean()))
+    SUMMARY_LINES.append("test_fullsize_properties[%s]: GPU ids == oracle ids on %.2f%% of 1000 queries at N = %d" % (config, 100 * same.mean(), N))
     assert same.mean() >= ID_BAR and np.allclose(od[same], d[:1000][same], rtol=1e-5, atol=1e-6)

@@ -21,7 +21,7 @@ def test_c_abi_replicas_answer_like_the_source(oracle_mod):
 
     X, Q = ds.sift_like(12000, 3001)  # odd batch: the last shard is shorter
     o = oracle_mod.OracleIndex.create("l2", 128, 12000, 16)
-    o.add(X, 64, threads=4)
+    o.add(X, 64)
     src = hip.DeviceIndex.upload(o.blob(), o.node_size, o.data_size, o.M, o.cur_nodes, "float32", "l2", 128)
     want = src.search(Q, 10, 80, stats=True)
     replicas = src.replicate([0, 0])
@@ -112,7 +112,7 @@ def test_index_view_shares_buffers_and_overlaps_launches(oracle_mod):
 
     X, Q = ds.sift_like(12000, 4000)
     o = oracle_mod.OracleIndex.create("l2", 128, 12000, 16)
-    o.add(X, 64, threads=4)
+    o.add(X, 64)
     src = hip.DeviceIndex.upload(o.blob(), o.node_size, o.data_size, o.M, o.cur_nodes, "float32", "l2", 128)
     view = src.view()
     assert view.device_buffers() == src.device_buffers()
@@ -137,3 +137,36 @@ def test_index_view_shares_buffers_and_overlaps_launches(oracle_mod):
     view.close()
     again = src.search(Q[:100], 10, 64)  # the source outlives its view
     assert np.array_equal(again[1], want[1][:100])
+
+
+def test_eight_shards_of_the_bench_shape_are_all_in_flight_together(oracle_mod):
+    # The 8-GPU shape of fnv_search_batch_multi on the ONE GPU of the test box (a device may be listed more than once):
+    # 80 000 host queries over eight handles = eight shards of 10 000, each driven by its own host thread through the
+    # chunked pinned pipeline.  Every shard must have been enqueued before ANY shard completed (eight devices would all be
+    # working at once), the caller's device stays what it was, and the bytes equal one handle's answer.
+    import torch
+
+    from flatnav_amd import hip
+
+    X, _ = ds.sift_like(40000, 1)
+    rng = np.random.default_rng(8)
+    Q = X[rng.integers(0, len(X), 80000)] + rng.integers(-3, 4, (80000, 128)).astype(np.float32)
+    o = oracle_mod.OracleIndex.create("l2", 128, 40000, 16)
+    o.add(X, 48)
+    src = hip.DeviceIndex.upload(o.blob(), o.node_size, o.data_size, o.M, o.cur_nodes, "float32", "l2", 128)
+    handles = [src] + src.replicate([0] * 7)
+    before = torch.cuda.current_device()
+    want = src.search(Q, 10, 64, stats=True)
+    hip.search_multi(handles, Q, 10, 64)  # warm: workspaces, plans, pinned staging
+    together = 0
+    for _ in range(4):
+        got = hip.search_multi(handles, Q, 10, 64, stats=True)
+        info = [h.launch_info() for h in handles]
+        together += 1 if max(i["enqueued_ns"] for i in info) < min(i["completed_ns"] for i in info) else 0
+    assert together >= 3, (together, info)
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
+    assert all(np.array_equal(got[2][k], want[2][k]) for k in ("count", "n_dist", "n_hops"))
+    assert torch.cuda.current_device() == before
+    # the same 80 000 queries through ONE handle's chunked pipeline (21 chunks alternating over two streams)
+    one = src.search(Q, 10, 64, stats=True)
+    assert np.array_equal(one[1], want[1]) and all(np.array_equal(one[2][k], want[2][k]) for k in ("count", "n_dist", "n_hops"))

@@ -169,6 +169,29 @@ def test_spill_paths_stay_exact(oracle_mod, hipmod):
         dev.search(Q, 10, 100)
 
 
+@pytest.mark.parametrize("tag_bits,slots", [(0, 256), (32, 384), (32, 256)])
+def test_stash_hands_over_to_the_bitmap_exactly(oracle_mod, hipmod, tag_bits, slots):
+    # The visited set's three levels on the DEVICE (tests/test_visited_model.py only models them on the CPU): a table of
+    # 256-384 slots at ef = 250 (~4500 ids per query) fills within the first hops, the 64-word stash behind it a few hops
+    # later, and from then on every id takes the path "both buckets full -> its stash bucket full -> HBM bitmap" while ids
+    # that did get a table or stash slot must still be found there.  16-bit tags, three 21-bit tags and two 32-bit tags per
+    # bucket; merged-beam kernel in registers and in LDS, and the two-heap kernel: ids, distance bits and the evaluation /
+    # hop counters equal the oracle's (a set that forgot or invented a member would change n_dist).
+    X, Q = ds.sift_like(20000, 500)
+    ix = _build(oracle_mod, "l2", "float32", X, 32)
+    o = ix.search(Q, 10, 250, stats=True)
+    dev = _upload(hipmod, ix)
+    dev.set_option("visited_tag_bits", tag_bits)
+    dev.set_option("visited_slots", slots)
+    for sorted_beam, registers in ((1, 1), (1, 0), (0, 1)):
+        dev.set_option("sorted_beam", sorted_beam)
+        dev.set_option("beam_registers", registers)
+        for _ in range(2):  # the second launch finds the slots' bitmaps handed back clean
+            _assert_exact(o, dev.search(Q, 10, 250, stats=True))
+        g = dev.launch_geometry()
+        assert g["visited_slots"] == slots and g["kernel"] == ("two_heaps" if not sorted_beam else "merged_beam_registers" if registers else "merged_beam_lds")
+
+
 @pytest.mark.parametrize("dt", ["float32", "uint8"])
 def test_wide_tag_visited_tables_stay_exact(oracle_mod, hipmod, dt):
     # Indexes beyond 2^24 nodes cannot use 16-bit tags at an affordable table size; the kernel then keeps three

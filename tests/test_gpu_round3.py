@@ -44,7 +44,7 @@ def test_rows_on_whole_lines_keep_every_bit(oracle_mod, hipmod, dt, dim, metric,
         X = rng.integers(lo, hi, (N, dim)).astype(dt)
         Q = rng.integers(lo, hi, (NQ, dim)).astype(dt)
     ix = oracle_mod.OracleIndex.create(metric, dim, N, 16, dt)
-    ix.add(X, 48, threads=8)
+    ix.add(X, 48)
     esize = 4 if dt == "float32" else 1
     rb16 = (dim * esize + 15) // 16 * 16
     rb128 = (rb16 + 127) // 128 * 128
@@ -74,7 +74,7 @@ def test_rows_on_whole_lines_keep_every_bit(oracle_mod, hipmod, dt, dim, metric,
                     assert all(np.array_equal(outs[0][2][k], other[2][k]) for k in ("count", "n_dist", "n_hops"))
                 else:  # another row configuration sums the same products in another order: float tolerance
                     same = (outs[0][1] == other[1]).all(axis=1)
-                    assert same.mean() >= 0.99 and np.allclose(outs[0][0][same], other[0][same], rtol=1e-5, atol=1e-6)
+                    assert same.mean() >= 0.999 and np.allclose(outs[0][0][same], other[0][same], rtol=1e-5, atol=1e-6)
     if dt != "float32":  # integer data: also bit-exact against the oracle in every layout
         od, ol, ost = ix.search(Q, 10, 150, stats=True)
         for dev in (plain, padded, always):
@@ -86,7 +86,7 @@ def test_rows_on_whole_lines_keep_every_bit(oracle_mod, hipmod, dt, dim, metric,
 def pick_cfg(nchunks):
     """csrc/kernel_table.h pick_row_cfg."""
     cfgs = [8, 16, 32, 64, 128, 256]
-    if nchunks > 128 and nchunks % 192 == 0:
+    if nchunks == 192:  # rows of exactly 3 KB: every lane loads its three chunks, the query lives in registers (round 4)
         return 6
     for c, span in enumerate(cfgs):
         if span >= nchunks:
@@ -97,7 +97,7 @@ def pick_cfg(nchunks):
 def test_tune_settles_the_kernel_choice_and_variants_can_be_pinned(oracle_mod, hipmod):
     X, Q = ds.sift_like(30000, 6000)  # integer-valued: ties -> the variants differ in speed, never in results
     ix = oracle_mod.OracleIndex.create("l2", 128, 30000, 16)
-    ix.add(X, 64, threads=8)
+    ix.add(X, 64)
     want = ix.search(Q, 10, 64, stats=True)
     dev = _upload(hipmod, ix)
     # without tuning, the first big launches of a beam width are exploratory samples
@@ -144,7 +144,7 @@ def test_tune_measures_the_lds_layout_and_never_changes_results(oracle_mod, hipm
     # ids, distances and counters stay the oracle's
     X, Q = ds.lowrank_normalized(40000, 4096, dim=100, rank=24, seed=100)
     ix = oracle_mod.OracleIndex.create("angular", 100, 40000, 32)
-    ix.add(X, 64, threads=8)
+    ix.add(X, 64)
     dev = _upload(hipmod, ix)
     for ef in (64, 128, 300):
         before = dev.search(Q, 10, ef, stats=True)
@@ -181,7 +181,7 @@ def test_small_launches_run_exact_shadows(oracle_mod, hipmod, case):
         X, Q = ds.lowrank_normalized(8000, 700, dim=100, rank=24, seed=100)
         dt, metric = "float32", "angular"
     ix = oracle_mod.OracleIndex.create(metric, X.shape[1], len(X), 16, dt)
-    ix.add(X, 48, threads=8)
+    ix.add(X, 48)
     dev = _upload(hipmod, ix)
     exact_ids = case != "f32_real"
     for ef, K in ((40, 10), (150, 25)):
@@ -196,8 +196,8 @@ def test_small_launches_run_exact_shadows(oracle_mod, hipmod, case):
                     assert np.array_equal(want[1][:nq], got[1]) and np.array_equal(want[0][:nq].view(np.uint32), got[0].view(np.uint32))
                     assert all(np.array_equal(want[2][k][:nq], got[2][k]) for k in ("count", "n_dist", "n_hops")), (case, nq, mode)
                 else:
-                    same = (want[1][:nq] == got[1]).all(axis=1)
-                    assert same.mean() >= 0.99 and np.allclose(want[0][:nq][same], got[0][same], rtol=1e-5, atol=1e-6)
+                    same = (want[1][:nq] == got[1]).all(axis=1)  # (the survey's float bar, as everywhere: 99.9 %)
+                    assert same.mean() >= 0.999 and np.allclose(want[0][:nq][same], got[0][same], rtol=1e-5, atol=1e-6)
         if case == "u8_every_query_ties":
             dev.set_option("shadow_exact", 1)
             dev.search(Q[:64], K, ef)
@@ -274,7 +274,7 @@ def test_multi_handle_search_overlaps_its_shards(oracle_mod, hipmod):
 
     X, Q = ds.sift_like(40000, 40000)
     ix = oracle_mod.OracleIndex.create("l2", 128, 40000, 16)
-    ix.add(X, 48, threads=8)
+    ix.add(X, 48)
     src = _upload(hipmod, ix)
     rep = src.replicate([0])[0]
     before = torch.cuda.current_device()

@@ -1,0 +1,170 @@
+"""Round 4 on the GPU, all through the C ABI and against the CPU oracle (bit-exact on integer-valued data):
+  * rows of exactly 3 KB keep their query in registers (csrc/distance.hpp `query_in_regs`): every kernel form, every element
+    type, a dimension that leaves the last chunk partly empty;
+  * large host-buffer searches run as a chunked pinned pipeline over two streams (`search_host_pipelined`): the bytes of one
+    launch, whatever the chunk plan (odd sizes, an exact last chunk after fnv_tune, pinned variants);
+  * `fnv_index_adopt`: a handle on buffers somebody else owns;
+  * options that cannot change the launch plan leave fnv_tune's result alone."""
+import numpy as np
+import pytest
+
+from flatnav_amd import datasets as ds
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hipmod():
+    from flatnav_amd import hip
+
+    assert hip.device_count() >= 1, "no MI355X visible"
+    return hip
+
+
+def _upload(hipmod, ix):
+    return hipmod.DeviceIndex.upload(ix.blob(), ix.node_size, ix.data_size, ix.M, ix.cur_nodes, ix.dtype, ix.metric, ix.dim)
+
+
+def _assert_exact(o, g, what=""):
+    od, ol, ost = o
+    gd, gl, gst = g
+    assert np.array_equal(ol, gl), "%s: ids differ in %d queries" % (what, int((ol != gl).any(axis=1).sum()))
+    assert np.array_equal(od.view(np.uint32), gd.view(np.uint32)), what
+    for k in ("count", "n_dist", "n_hops"):
+        assert np.array_equal(ost[k], gst[k]), (what, k)
+
+
+@pytest.mark.parametrize("dt,dim,metric", [("float32", 768, "angular"), ("float32", 768, "l2"), ("float32", 760, "l2"),
+                                           ("uint8", 3072, "l2"), ("int8", 3060, "angular")])
+def test_three_kilobyte_rows_keep_the_query_in_registers(oracle_mod, hipmod, dt, dim, metric):
+    # 192-chunk rows: G = 64 lanes x CU = 3 chunks, the query is 12 registers per lane and takes no LDS.  Integer-valued
+    # data, so every summation order gives the same bits: ids, distance bits and the per-query counters equal the oracle's
+    # in the two-heap kernel, the merged-beam kernel with 1 / 2 / 4 register chunks and in LDS, with the batched entry scan
+    # (K0 fills the registers from its LDS tile) and in the device builder's wiring kernels.
+    rng = np.random.default_rng(dim)
+    N, NQ = 3000, 200
+    hi = {"float32": 12, "uint8": 6, "int8": 4}[dt]
+    lo = -3 if dt == "int8" else 0
+    X = rng.integers(lo, hi, (N, dim)).astype(dt)
+    Q = rng.integers(lo, hi, (NQ, dim)).astype(dt)
+    ix = oracle_mod.OracleIndex.create(metric, dim, N, 16, dt)
+    ix.add(X, 48)
+    dev = _upload(hipmod, ix)
+    assert dev.row_bytes == 3072
+    lds = {}
+    for ef, K in ((20, 5), (100, 10), (200, 10), (300, 20)):
+        want = ix.search(Q, K, ef, stats=True)
+        for name, opts in (("two_heaps", dict(sorted_beam=0)), ("merged_registers", dict(sorted_beam=1, beam_registers=1)),
+                           ("merged_lds", dict(sorted_beam=1, beam_registers=0)), ("entry_kernel", dict(sorted_beam=1, entry_kernel=1))):
+            for k, v in dict(sorted_beam=2, beam_registers=1, entry_kernel=0, **opts).items():
+                dev.set_option(k, v)
+            _assert_exact(want, dev.search(Q, K, ef, stats=True), "%s ef=%d" % (name, ef))
+            lds[(name, ef)] = dev.launch_geometry()["lds_bytes"]
+    # no LDS for the query: a slot is no bigger than that of a 128-d index of the same size (whose 512-byte query IS in LDS)
+    if dt == "float32" and dim == 768:
+        Xs = rng.integers(0, 12, (N, 128)).astype(np.float32)
+        ixs = oracle_mod.OracleIndex.create(metric, 128, N, 16, dt)
+        ixs.add(Xs, 48)
+        devs = _upload(hipmod, ixs)
+        devs.set_option("sorted_beam", 1)
+        devs.search(Xs[:64], 10, 100)
+        assert lds[("merged_registers", 100)] <= devs.launch_geometry()["lds_bytes"], (lds, devs.launch_geometry())
+    # the device builder's kernels read their staged vectors into the same registers: sequential insertion = the oracle's graph
+    import flatnav_amd as flatnav
+
+    if dt == "float32":
+        index = flatnav.index.create(metric, dim, 600, 16)
+        index.add(X[:100], 48)
+        for i in range(100, 600, 1):
+            index.add(X[i:i + 1], 48, device=True)
+        small = oracle_mod.OracleIndex.create(metric, dim, 600, 16, dt)
+        small.add(X[:600], 48)
+        assert np.array_equal(np.asarray(index._raw_blob()).reshape(-1)[: 600 * small.node_size], small.blob()[: 600 * small.node_size])
+
+
+@pytest.mark.parametrize("dt", ["float32", "uint8"])
+def test_pipelined_host_search_returns_the_single_launch_bytes(oracle_mod, hipmod, dt):
+    # Host-buffer batches above the 1 MB pinned buffer go out in chunks of 512, 1024, 2048, 4096 ... queries alternating
+    # over two streams.  Whatever the chunk plan -- odd sizes, one query more than a chunk boundary, the small exact last
+    # chunk that a tuned tail variant asks for, a pinned variant -- ids, distances, counts and counters are the oracle's,
+    # null output arrays are left alone, and the caller's arrays are only written inside [0, nq).
+    X, Q = ds.sift_like(20000, 12000)
+    X, Q = X.astype(dt), Q.astype(dt)
+    ix = oracle_mod.OracleIndex.create("l2", 128, 20000, 16, dt)
+    ix.add(X, 48)
+    dev = _upload(hipmod, ix)
+    K, ef = 10, 64
+    want = ix.search(Q, K, ef, stats=True, threads=8)
+    for nq in (12000, 3585, 3584, 2049, 7681, 1024 if dt == "uint8" else 2100):
+        got = dev.search(Q[:nq], K, ef, stats=True)
+        _assert_exact(tuple(w[:nq] if not isinstance(w, dict) else {k: v[:nq] for k, v in w.items()} for w in want), got, "nq=%d" % nq)
+    # after fnv_tune (integer-valued data: a tail variant wins, so the last chunk is 1024 queries of the two-heap kernel)
+    dev.tune(Q[:10000], K, ef)
+    tuned = dev.search(Q, K, ef, stats=True)
+    _assert_exact(want, tuned, "tuned")
+    for variant in (0, 1, 3):
+        dev.set_option("sorted_variant", variant)
+        _assert_exact(want, dev.search(Q, K, ef, stats=True), "variant %d" % variant)
+    dev.set_option("sorted_variant", -1)
+    # a view of the handle (no pipeline of its own) and the handle itself agree; closing order is free of surprises
+    view = dev.view()
+    _assert_exact(want, view.search(Q, K, ef, stats=True), "view")
+    view.close()
+    _assert_exact(want, dev.search(Q, K, ef, stats=True), "after the view")
+    # wide beams through the same path (LDS form of the merged-beam kernel, spills of the visited set)
+    dev.set_option("visited_slots", 512)
+    w2 = ix.search(Q[:3000], 5, 300, stats=True, threads=8)
+    _assert_exact(w2, dev.search(Q[:3000], 5, 300, stats=True), "ef=300")
+
+
+def test_adopted_buffers_answer_like_their_owner(oracle_mod, hipmod):
+    # fnv_index_adopt: a second, independent handle (own workspace, stream, options) on buffers the first one owns
+    X, Q = ds.sift_like(8000, 700)
+    ix = oracle_mod.OracleIndex.create("l2", 128, 8000, 16)
+    ix.add(X, 48)
+    want = ix.search(Q, 10, 80, stats=True)
+    owner = _upload(hipmod, ix)
+    guest = hipmod.DeviceIndex.adopt(owner.device_buffers(), owner.M, owner.n_nodes, "float32", "l2", 128, keep_alive=owner)
+    assert guest.device_buffers() == owner.device_buffers() and guest.row_bytes == owner.row_bytes
+    guest.set_option("sorted_beam", 0)  # its options are its own
+    _assert_exact(want, guest.search(Q, 10, 80, stats=True), "guest")
+    assert guest.launch_geometry()["kernel"] == "two_heaps"
+    _assert_exact(want, owner.search(Q, 10, 80, stats=True), "owner")
+    assert owner.launch_geometry()["kernel"] != "two_heaps"
+    guest.close()  # never frees what it does not own
+    _assert_exact(want, owner.search(Q, 10, 80, stats=True), "owner after the guest left")
+    with pytest.raises(ValueError):
+        hipmod.DeviceIndex.adopt([(owner.device_buffers()[0][0] + 4, 0)] + owner.device_buffers()[1:], owner.M, owner.n_nodes,
+                                 "float32", "l2", 128)  # a misaligned vector table
+
+
+def test_unrelated_options_leave_the_tuning_alone(oracle_mod, hipmod):
+    # Index.h::addBatchDevice flips output_node_ids around every device build; that (and shadow_exact,
+    # tune_layout) must not throw fnv_tune's measurements away -- options that change the plan still do.  (Device-pointer
+    # entry point: that is where the adaptive choice lives; the host pipeline never runs an exploratory launch.)
+    import torch
+
+    X, Q = ds.sift_like(20000, 4096)
+    ix = oracle_mod.OracleIndex.create("l2", 128, 20000, 16)
+    ix.add(X, 48)
+    dev = _upload(hipmod, ix)
+    dq = torch.from_numpy(Q).cuda()
+    od = torch.empty((4096, 10), dtype=torch.float32, device="cuda")
+    ol = torch.empty((4096, 10), dtype=torch.int32, device="cuda")
+
+    def launch():
+        dev.search_device(dq.data_ptr(), 4096, 10, 64, 100, od.data_ptr(), ol.data_ptr())
+        torch.cuda.synchronize()
+        return dev.launch_info()
+
+    dev.tune(int(dq.data_ptr()), 10, 64, nq=4096)
+    settled = launch()
+    assert not settled["exploratory"]
+    for name in ("output_node_ids", "shadow_exact", "tune_layout"):
+        dev.set_option(name, 0)
+        dev.set_option(name, 1)
+    dev.set_option("output_node_ids", 0)
+    again = launch()
+    assert not again["exploratory"] and again["variant_id"] == settled["variant_id"]
+    dev.set_option("visited_factor", 20)  # changes the table size rule: measurements are void
+    assert launch()["exploratory"]

@@ -50,7 +50,11 @@ def _worker(rank, world, port, out_dir):
         blob = torch.empty(N * node, dtype=torch.uint8)
     # split like the device does (three buffers) and replicate with one broadcast each
     bufs = [blob[: N * node // 3], blob[N * node // 3: 2 * (N * node // 3)], blob[2 * (N * node // 3):]]
-    multigpu.broadcast_buffers(bufs, src=0)
+    # ... in pieces of at most 10 000 bytes: the same code path that moves a 32 GB vector table as 16 collectives of 2 GB
+    stats = multigpu.broadcast_buffers(bufs, src=0, piece_bytes=10_000)
+    assert [st["bytes"] for st in stats] == [b.numel() for b in bufs]
+    assert [st["pieces"] for st in stats] == [-(-b.numel() // 10_000) for b in bufs] and min(st["pieces"] for st in stats) > 1
+    assert all(st["seconds"] > 0 and st["GBps"] > 0 for st in stats)
     replica = orc.OracleIndex.from_blob("l2", "float32", dim, N, N, M, blob.numpy())
     lo, hi = multigpu.shard_bounds(Qn, world, rank)
     d, l = replica.search(Q[lo:hi], 10, 50)
