@@ -212,12 +212,21 @@ struct IndexOptions {
           cand_slots = 0, spill_entries = 16384, blocks_per_cu = 0, visited_wide = 0,
           entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0, sorted_beam = 2,
           sorted_beam_min = 1, sorted_cand_lds = 2, sorted_tail_exact_pct = -1, beam_registers = 1,
-          sorted_variant = -1, tune_layout = 1, shadow_exact = 1;
+          sorted_variant = -1, tune_layout = 1, shadow_exact = 1, host_pipeline = 1;
   int64_t overflow_list = -1;  // -1: automatic (a list in HBM only when the bitmap is larger than 512 KB)
 };
 
-constexpr int kNumVariants = 6;
-static const int kTailPct[kNumVariants] = {0, 0, 50, 75, 100, 25};
+// Kernel variants of one launch: 0 the exact two-heap kernel, 1 the merged-beam kernel, 2-5 the merged-beam kernel with
+// the last 50 / 75 / 100 / 25 % of a round of queries sent straight to the exact search, 6 (round 4) the merged-beam kernel
+// for every query plus exact shadows of the last ones on the slots the drain leaves idle (search_params.h).
+constexpr int kNumVariants = 7;
+constexpr int kVariantTailShadows = 6;
+static const int kTailPct[kNumVariants] = {0, 0, 50, 75, 100, 25, 0};
+static inline bool variant_allowed(int v, bool multi_round, bool try_tail, bool shadows_on) {
+  if (v < 2) return true;
+  if (v == kVariantTailShadows) return shadows_on;
+  return multi_round && try_tail;  // an exact tail needs more than one round of queries
+}
 
 struct fnv_index_s : IndexOptions {
   bool owns_buffers = true;  // false: a view (fnv_index_view) of another handle's vectors / links / labels
@@ -239,8 +248,8 @@ struct fnv_index_s : IndexOptions {
   struct Tuner {
     // ms per query: [0] two-heap kernel, [1] merged-beam kernel, [2..5] merged-beam kernel whose last 50 / 75 / 100 / 25 %
     // of a round of queries go straight to the exact search ("sorted_tail_exact_pct"; launches of more than one round)
-    float best[kNumVariants] = {-1.f, -1.f, -1.f, -1.f, -1.f, -1.f};
-    int samples[kNumVariants] = {0, 0, 0, 0, 0, 0};
+    float best[kNumVariants] = {-1.f, -1.f, -1.f, -1.f, -1.f, -1.f, -1.f};
+    int samples[kNumVariants] = {0, 0, 0, 0, 0, 0, 0};
   };
   // Per beam width: the LDS layout fnv_tune measured to be the fastest (absent: the rules of configure_launch).
   struct LayoutChoice {
@@ -670,17 +679,18 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   else if (n == "sorted_tail_exact_pct") ix->sorted_tail_exact_pct = value;
   else if (n == "beam_registers") ix->beam_registers = value;
   else if (n == "sorted_variant") {
-    if (value >= kNumVariants) return fail(FNV_ERR_INVALID, "sorted_variant must be -1 (adaptive) or 0..5");
+    if (value >= kNumVariants) return fail(FNV_ERR_INVALID, "sorted_variant must be -1 (adaptive) or 0..6");
     ix->sorted_variant = value;
   }
   else if (n == "visited_tag_bits") ix->visited_tag_bits = value;
   else if (n == "tune_layout") ix->tune_layout = value;
   else if (n == "shadow_exact") ix->shadow_exact = value;
+  else if (n == "host_pipeline") ix->host_pipeline = value;
   else return fail(FNV_ERR_INVALID, "unknown option: " + n);
   // What fnv_tune measured (kernel variant, LDS layout) stays valid across options that change neither the launch plan
   // nor the kernel choice: Index.h::addBatchDevice flips output_node_ids around every device build, and a tune costs
   // dozens of launches.  (output_node_ids is read per launch; shadow_exact per launch; tune_layout by fnv_tune itself.)
-  const bool keeps_tuning = n == "output_node_ids" || n == "shadow_exact" || n == "tune_layout";
+  const bool keeps_tuning = n == "output_node_ids" || n == "shadow_exact" || n == "tune_layout" || n == "host_pipeline";
   if (!keeps_tuning) {
     ix->options_version++;
     ix->tuner.clear();
@@ -972,8 +982,10 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   int64_t tail_pct = ix->sorted_tail_exact_pct < 0 ? 0 : ix->sorted_tail_exact_pct;
   bool exploratory = false;
   const int pinned = force_variant >= 0 ? force_variant : (int)ix->sorted_variant;  // fnv_tune / "sorted_variant"
+  const bool shadows_on = ix->shadow_exact != 0;
+  const bool try_tail = ix->sorted_tail_exact_pct < 0;
   if (sorted && pinned >= 0) {
-    variant = (pinned >= 2 && !multi_round) ? 1 : pinned;  // an exact tail needs more than one round of queries
+    variant = variant_allowed(pinned, multi_round, true, shadows_on) ? pinned : 1;
     sorted = variant != 0;
     if (variant >= 2) tail_pct = kTailPct[variant];
   } else if (sorted && ix->sorted_beam == 2) {
@@ -989,18 +1001,18 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     }
     if (nq >= 2048) {
       fnv_index_s::Tuner& t = ix->tuner[2 * B + (multi_round ? 1 : 0)];
-      const bool try_tail = multi_round && ix->sorted_tail_exact_pct < 0;
       // three samples each (the first launch of a kernel is a cold one; the best of the rest decides), then the fastest
       // (fnv_tune takes all the samples in one call, so that no caller's launch is an exploratory one)
-      const int nvar = try_tail ? kNumVariants : 2;
       variant = -1;
-      for (int v : {1, 0, 4, 3, 2, 5})
-        if (v < nvar && variant < 0 && t.samples[v] < 3) variant = v;
+      for (int v : {1, 0, 6, 4, 3, 2, 5})
+        if (variant_allowed(v, multi_round, try_tail, shadows_on) && variant < 0 && t.samples[v] < 3) variant = v;
       exploratory = variant >= 0;
       if (variant < 0) {
         variant = 0;
-        for (int v = 1; v < nvar; v++)
-          if (t.best[v] < t.best[variant] || (v == 1 && t.best[1] <= t.best[0])) variant = v;
+        for (int v = 1; v < kNumVariants; v++)
+          if (variant_allowed(v, multi_round, try_tail, shadows_on) && t.samples[v] > 0 &&
+              (t.best[v] < t.best[variant] || (v == 1 && t.best[1] <= t.best[0])))
+            variant = v;
       }
       sample = t.samples[variant] < 4;
       sorted = variant != 0;
@@ -1016,13 +1028,15 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   // a query that needs none stops at its next hop.  Same bytes either way.
   const bool shadow = sorted && ix->shadow_exact != 0 && 4 * nq <= (uint64_t)bpc * (uint64_t)ix->num_cus;
   const uint32_t nslots = shadow ? (uint32_t)(2 * nq) : (uint32_t)std::min<uint64_t>(nq, (uint64_t)bpc * (uint64_t)ix->num_cus);
+  // Tail shadows (variant 6, search_params.h): one exact shadow per slot at most -- of the queries dispensed last
+  const uint32_t tail_shadows = (sorted && !shadow && variant == kVariantTailShadows) ? (uint32_t)std::min<uint64_t>(nq, nslots) : 0u;
   const uint32_t max_slots = std::max<uint32_t>(nslots, (uint32_t)std::min<uint64_t>(nq, (uint64_t)std::max(plan.bpc, plan.sbpc) * (uint64_t)ix->num_cus));
 
   // ---- workspace (grown on demand; sized for whichever kernel keeps more slots resident) -------------------------
   int rc = grow((void**)&ix->d_bitmap, &ix->bitmap_bytes, (size_t)max_slots * plan.heaps.bitmap_words * 4, true);
   if (!rc) rc = grow((void**)&ix->d_ovf, &ix->ovf_bytes, (size_t)max_slots * plan.heaps.ovf_cap * 4);
   if (!rc) rc = grow((void**)&ix->d_spill, &ix->spill_bytes, (size_t)max_slots * plan.heaps.spill_entries * 8);
-  if (!rc && shadow) rc = grow((void**)&ix->d_done, &ix->done_bytes, (size_t)nq * 4);
+  if (!rc && (shadow || tail_shadows)) rc = grow((void**)&ix->d_done, &ix->done_bytes, (size_t)nq * 4);
   if (rc) return rc;
 
   SearchParams p = sorted ? plan.sorted : plan.heaps;
@@ -1068,6 +1082,13 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     HIP_TRY(hipGetLastError());
     p.entry_node = p.entry_node_out;
     p.entry_dist = p.entry_dist_out;
+  }
+  if (tail_shadows) {  // the queries, then exact shadows of the last `tail_shadows` of them (pulled by slots that would go idle)
+    HIP_TRY(hipMemsetAsync(ix->d_done, 0, (size_t)nq * 4, stream));
+    p.shadow_base = (uint32_t)nq;
+    p.done_flags = ix->d_done;
+    p.nq = (uint32_t)(nq + tail_shadows);
+    p.tail_exact = 0u;
   }
   if (shadow) {  // from here on the launch has 2 nq work items: the queries, then their exact shadows
     HIP_TRY(hipMemsetAsync(ix->d_done, 0, (size_t)nq * 4, stream));
@@ -1242,7 +1263,8 @@ static int search_host_pipelined(fnv_index_t ix, const void* queries, uint64_t n
     }
     if (ix->sorted_variant >= 0) chunk_variant = ix->sorted_variant == 0 ? 0 : 1, tuned = (int)ix->sorted_variant;
   }
-  const bool exact_last = tuned >= 2;
+  const bool exact_last = tuned >= 2 && tuned != kVariantTailShadows;
+  const bool shadow_last = tuned == kVariantTailShadows;  // the last chunk gets exact shadows on the slots its drain leaves idle
   // ---- chunk plan
   std::vector<uint64_t> lo, cnt;
   {
@@ -1316,7 +1338,7 @@ static int search_host_pipelined(fnv_index_t ix, const void* queries, uint64_t n
     int32_t* oc = (int32_t*)(o + n * K * 8);
     uint64_t* ond = (uint64_t*)(o + ((n * K * 8 + n * 4 + 7) & ~(size_t)7));
     uint64_t* onh = ond + n;
-    const int variant = (exact_last && c + 1 == nchunk && nchunk > 1) ? 0 : chunk_variant;
+    const int variant = (c + 1 == nchunk && nchunk > 1) ? (exact_last ? 0 : shadow_last ? kVariantTailShadows : chunk_variant) : chunk_variant;
     int rc = search_device_impl(h, dq + lo[c] * qrow, n, K, ef_search, num_initializations, od, ol, oc, ond, onh, h->stream,
                                 ix->output_node_ids != 0, variant);
     if (rc) {
@@ -1362,7 +1384,7 @@ int fnv_search_batch(fnv_index_t ix, const void* queries, uint64_t nq, int K, in
     const size_t qbytes = (size_t)nq * ix->dim * dtype_size(ix->dtype);
     const size_t obytes = (size_t)nq * ((size_t)K * 8 + 4 + 8 + 8) + 64;
     const bool small = ((qbytes + 63) & ~(size_t)63) + ((obytes + 63) & ~(size_t)63) + 128 <= (1u << 20);
-    if (!small && nq >= 1024 && !ix->parent)  // (a view has no view of its own: it takes the plain path)
+    if (!small && nq >= 1024 && !ix->parent && ix->host_pipeline != 0)  // (a view has no view of its own: it takes the plain path)
       return search_host_pipelined(ix, queries, nq, K, ef_search, num_initializations, out_dist, out_labels, out_count, out_ndist,
                                    out_nhops);
   }
@@ -1628,10 +1650,13 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
     if (r) return r;
     const bool multi = nq > (uint64_t)ix->plan.sbpc * (uint64_t)ix->num_cus;
     if (multi && ix->sorted_tail_exact_pct < 0 && (r = time_variant(3, 4, &t4)) != FNV_OK) return r;
+    float t6 = -1.f;
+    if (ix->shadow_exact != 0 && (r = time_variant(kVariantTailShadows, 4, &t6)) != FNV_OK) return r;
     *out = (t4 > 0.f && t4 < t1) ? t4 : t1;
+    if (t6 > 0.f && t6 < *out) *out = t6;
     if (tune_log)
-      fprintf(stderr, "fnv_tune B=%d layout %zu (heap in LDS %d, table %u): merged %.4f ms, 75%% tail exact %.4f ms -> %u slots, %d per CU\n", B,
-              li, (int)cands[li].cand_lds, cands[li].vis_slots, t1 * (float)nq, t4 * (float)nq, (unsigned)ix->geom[4], (int)ix->geom[3]);
+      fprintf(stderr, "fnv_tune B=%d layout %zu (heap in LDS %d, table %u): merged %.4f ms, 75%% tail exact %.4f ms, tail shadows %.4f ms -> %u slots, %d per CU\n", B,
+              li, (int)cands[li].cand_lds, cands[li].vis_slots, t1 * (float)nq, t4 * (float)nq, t6 * (float)nq, (unsigned)ix->geom[4], (int)ix->geom[3]);
     return FNV_OK;
   };
   // The device settles first.  After the GPU has idled (the caller computed something on the host) the first launches run
@@ -1654,14 +1679,14 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
   for (size_t li = 0; li < cands.size(); li++) {
     float t = -1.f;
     if (time_layout(li, &t) != FNV_OK) continue;  // e.g. a layout that does not fit LDS: not a candidate
-    if (best_layout_t < 0.f || t < best_layout_t * 0.98f) {  // a neighbour must win by more than noise
+    if (best_layout_t < 0.f || t < best_layout_t * 0.95f) {  // a neighbour must win by 5 %: less is box-to-box noise (round 4: a 2 % margin picked layouts that lost 5 % under the bench protocol)
       best_layout_t = t;
       best_layout = li;
     }
   }
   if (best_layout != 0) {  // a neighbour won: the rules' layout was timed first, so it is timed once more, now last
     float again = -1.f;
-    if (time_layout(0, &again) == FNV_OK && !(best_layout_t < again * 0.98f)) best_layout = 0;
+    if (time_layout(0, &again) == FNV_OK && !(best_layout_t < again * 0.95f)) best_layout = 0;
   }
   {
     std::lock_guard<std::mutex> lock(ix->mu);
@@ -1675,9 +1700,9 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
 
   // ---- 2. the kernel variant on that layout --------------------------------------------------------------------------
   const bool multi_round = nq > (uint64_t)ix->plan.sbpc * (uint64_t)ix->num_cus;
-  const int nvar = (multi_round && ix->sorted_tail_exact_pct < 0) ? kNumVariants : 2;
   fnv_index_s::Tuner t;
-  for (int v = 0; v < nvar; v++) {
+  for (int v = 0; v < kNumVariants; v++) {
+    if (!variant_allowed(v, multi_round, ix->sorted_tail_exact_pct < 0, ix->shadow_exact != 0)) continue;
     rc = time_variant(v, 4, &t.best[v]);
     if (rc) return rc;
     if (tune_log) fprintf(stderr, "fnv_tune B=%d variant %d: %.4f ms\n", B, v, t.best[v] * (float)nq);

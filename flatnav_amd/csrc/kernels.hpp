@@ -286,7 +286,7 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, const Query<G, CU
     cand_n--;
     n_hops++;
     PH_MARK(2);
-    if (stop && rfl((int)stop_now) != 0) {  // the merged-beam pass has answered this query
+    if (stop && rfl((int)stop_now) == (int)SH_ANSWERED) {  // the merged-beam pass has answered this query
       aborted = true;
       break;
     }
@@ -394,7 +394,7 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, const Query<G, CU
   // the results it wrote are then overwritten by the right ones, the status stays set -- conservative.)
   if (err && stop) {
     const uint32_t answered = __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (rfl((int)answered) != 0) aborted = true;
+    if (rfl((int)answered) == (int)SH_ANSWERED) aborted = true;
   }
   if (aborted) {  // nothing to report; hand the slot's HBM bitmap back clean
     if (ovf) clear_spill_bitmap(bitmap, ovf_list, ovf_glist, tagged, lane);

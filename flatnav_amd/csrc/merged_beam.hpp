@@ -119,10 +119,15 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
   while (true) {
     const int item = next_query(lane);
     if (item < 0) break;
-    // shadow mode (search_params.h): items >= shadow_base are exact searches of query item - shadow_base
+    // shadows (search_params.h): items >= shadow_base are exact searches of the LAST queries, most recent first
     const uint32_t shadow_base = cold_args()->shadow_base;
     const bool shadow = shadow_base != 0u && (uint32_t)item >= shadow_base;
-    const int qi = shadow ? item - (int)shadow_base : item;
+    const int qi = shadow ? 2 * (int)shadow_base - 1 - item : item;
+    if (shadow) {  // claim the query (0 -> SH_SHADOW): answered already, or its own wave is searching it again -> nothing to do
+      uint32_t old = 0u;
+      if (lane == 0) old = atomicCAS(cold_args()->done_flags + qi, SH_NONE, SH_SHADOW);
+      if (rfl((int)old) != (int)SH_NONE) continue;
+    }
     PH_DECL
     // Per-query constants are re-read from the kernel arguments at the top of every query (a dozen scalar loads) and
     // again by the exact re-run below: nothing but the loop itself is then live across the two code paths, so the
@@ -520,10 +525,17 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
         atomicAdd(rc + tie, 1u);
       }
       if (ovf) clear_spill_bitmap(bitmap, ovf_list, ovf_glist, true, lane);
-      if (shadow_base != 0u && !shadow) {  // its shadow has been searching this query exactly since the launch began
-        PH_FLUSH;
-        __syncthreads();
-        continue;
+      // a query in the shadowed range: whoever claims it first searches it exactly -- a shadow that is already under way
+      // (then this wave moves on: the answer comes one exact-search latency after the QUERY started, not after this pass
+      // ended), else this wave itself (and no shadow will start on it any more)
+      if (shadow_base != 0u && !shadow && (uint32_t)qi + (c->nq - shadow_base) >= shadow_base) {
+        uint32_t old = 0u;
+        if (lane == 0) old = atomicCAS(c->done_flags + qi, SH_NONE, SH_OWN_RERUN);
+        if (rfl((int)old) == (int)SH_SHADOW) {
+          PH_FLUSH;
+          __syncthreads();
+          continue;
+        }
       }
       reset_visited(vis, ovf_list, true, lane);
       __syncthreads();
@@ -573,8 +585,8 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WA
         if (c->out_count) c->out_count[qi] = cnt;
         if (c->out_ndist) c->out_ndist[qi] = n_dist;
         if (c->out_nhops) c->out_nhops[qi] = n_hops;
-        // answered: the shadow may stop (it writes the same bytes if it gets there first, so no ordering is needed)
-        if (shadow_base != 0u) __hip_atomic_store(c->done_flags + qi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // answered: a shadow stops / never starts (it writes the same bytes if it gets there first, so no ordering is needed)
+        if (shadow_base != 0u) __hip_atomic_store(c->done_flags + qi, SH_ANSWERED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     if (ovf) clear_spill_bitmap(bitmap, ovf_list, ovf_glist, true, lane);

@@ -51,6 +51,7 @@ constexpr int MB_R = 4;                   // merged-beam kernel: 64-entry chunks
 constexpr int MB_MAX_BEAM = MB_R * WAVE;  // ... = the widest beam it serves
 
 enum : int { ST_OK = 0, ST_CAND_OVERFLOW = 1 };
+enum : uint32_t { SH_NONE = 0u, SH_ANSWERED = 1u, SH_SHADOW = 2u, SH_OWN_RERUN = 3u };  // done_flags (exact shadows, below)
 constexpr int SCAN_WAVES = 4;  // entry_scan_kernel (K0): waves per workgroup ...
 constexpr int SCAN_QPB = 32;   // ... and queries per workgroup
 constexpr uint32_t OVF_LIST = 30;  // ids remembered for a cheap clean-up of the HBM visited bitmap
@@ -101,10 +102,19 @@ struct SearchParams {
   uint32_t off_stage_d;     // LDS: [WAVE + 1] distances of a link row's unvisited neighbours (merged-beam kernel; = off_nbr:
                             // the permutation buffer is idle while they are staged)
   uint32_t tail_exact;     // merged-beam kernel: the last tail_exact queries of the launch skip the sorted pass
-  // Shadow mode (small launches: every query and its shadow are resident from the start): work items >= shadow_base are
-  // exact (two-heap) searches of query item - shadow_base, started TOGETHER with the merged-beam search of the same query;
-  // the merged-beam pass never re-runs a query (its shadow is already under way) and tells the shadow to stop when it
-  // finishes without a tie.  0 = off.  done_flags: [shadow_base] words, zero at launch.
+  // Exact shadows.  Work items >= shadow_base (= the number of queries) are exact (two-heap) searches of the LAST queries of
+  // the launch, most recently dispensed first: item shadow_base + k shadows query shadow_base - 1 - k; nq (the dispenser's
+  // limit) = queries + shadows.  A slot only ever pulls a shadow once every query has been handed out, i.e. when it would
+  // otherwise go idle, and the queries it shadows first are the ones whose merged-beam search has only just begun.  One
+  // word per query, done_flags[shadow_base] (zero at launch), settles who answers it:
+  //   SH_NONE -> SH_ANSWERED    its merged-beam pass finished without a tie: a shadow stops at its next hop / never starts
+  //   SH_NONE -> SH_SHADOW      a shadow claimed it: a merged-beam pass that meets a tie later does NOT search it again
+  //   SH_NONE -> SH_OWN_RERUN   the merged-beam pass met a tie first and searches it again itself: no shadow starts
+  // Both write the same bytes when both finish.  Two uses: small launches (at most a quarter of the slots: every query has a
+  // shadow from the start; round 3) and -- round 4, "tail shadows" -- the end of ANY launch: instead of sending the whole last
+  // round through the slower exact kernel so that no re-run becomes a straggler, every query runs the merged-beam kernel and
+  // the slots that the drain leaves idle run the exact search of the queries still under way; a tie then costs one
+  // exact-search latency from the query's start, paid by a slot that had nothing else to do.  0 = off.
   uint32_t shadow_base;
   uint32_t* done_flags;
 };

@@ -295,7 +295,7 @@ class DeviceIndex:
         r = (C.c_uint64 * 4)()
         check(lib().fnv_last_launch_info(self._h, r))
         names = ["two_heaps", "merged_beam", "merged_beam_tail50", "merged_beam_tail75", "merged_beam_tail100",
-                 "merged_beam_tail25"]
+                 "merged_beam_tail25", "merged_beam_tail_shadows"]
         return {"variant": names[int(r[0])], "variant_id": int(r[0]), "exploratory": bool(int(r[1]) & 1),
                 "shadow": bool(int(r[1]) & 2),
                 "enqueued_ns": int(r[2]), "completed_ns": int(r[3])}

@@ -183,14 +183,22 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *                     variant for the adaptive choice to measure (it tries 0, 25, 50, 75 and 100); >= 0 = fixed
  *   "beam_registers"  != 0 (default): beams of at most 256 entries keep the sorted array in registers (the merge's
  *                     permutation goes through LDS); 0 = the array always lives in LDS, as it does for wider beams
- *   "sorted_variant"  -1 (default) = the adaptive choice above; 0..5 = pin what a merged-beam-capable launch runs:
+ *   "sorted_variant"  -1 (default) = the adaptive choice above; 0..6 = pin what a merged-beam-capable launch runs:
  *                     0 two-heap kernel, 1 merged-beam kernel, 2 / 3 / 4 / 5 merged-beam kernel with the last 50 / 75 /
- *                     100 / 25 % of a round straight to the exact search (launches of one round or less run 1 instead)
+ *                     100 / 25 % of a round straight to the exact search (launches of one round or less run 1 instead),
+ *                     6 (round 4) merged-beam kernel for every query plus exact "tail shadows": the slots that run out of
+ *                     queries search the most recently started ones exactly, so a tie in the last round costs one
+ *                     exact-search latency from the query's start without the whole round paying for the slower kernel
+ *                     (needs "shadow_exact" != 0, else 1 runs)
  *   "shadow_exact"    1 (default): a launch that fills at most a quarter of the resident query slots (a single query, a
  *                     batch of 64 ...) starts, next to the merged-beam search of every query, an exact two-heap search of
  *                     the same query on another slot; a query in which equal distances meet at a decision is then
  *                     answered after one exact-search latency from the start of the launch instead of a merged-beam pass
  *                     plus a re-run, the shadow of a query that needs none stops at its next hop.  0 = off.  Same bytes.
+ *   "host_pipeline"   1 (default): host-buffer batches above the 1 MB pinned staging buffer are searched in chunks (512,
+ *                     1024, 2048, then 4096 queries) staged through pinned memory, alternating over two streams, so that
+ *                     staging, copies and searches overlap (fnv_search_batch); 0 = one pageable copy in, one launch, copies
+ *                     out (what tests of single-launch behaviour and A/B measurements want).  Same bytes.
  *   "tune_layout"     1 (default): fnv_tune also measures the LDS layout (see fnv_tune); 0 = kernel variants only
  *   "sorted_beam_min" smallest beam width the merged-beam kernel is used for (default 1)
  *   "sorted_cand_lds" where the exact re-run of the merged-beam kernel keeps its candidates heap: 2 (default) = in LDS

@@ -25,7 +25,9 @@ def hipmod():
 
 
 def _upload(hipmod, ix):
-    return hipmod.DeviceIndex.upload(ix.blob(), ix.node_size, ix.data_size, ix.M, ix.cur_nodes, ix.dtype, ix.metric, ix.dim)
+    dev = hipmod.DeviceIndex.upload(ix.blob(), ix.node_size, ix.data_size, ix.M, ix.cur_nodes, ix.dtype, ix.metric, ix.dim)
+    dev.set_option("host_pipeline", 0)  # one host batch = one launch (the chunked pipeline is test_gpu_round4.py's subject)
+    return dev
 
 
 @pytest.mark.parametrize("dt,dim,metric", [("float32", 100, "angular"), ("uint8", 100, "l2"), ("float32", 200, "l2"),
@@ -100,41 +102,53 @@ def test_tune_settles_the_kernel_choice_and_variants_can_be_pinned(oracle_mod, h
     ix.add(X, 64)
     want = ix.search(Q, 10, 64, stats=True)
     dev = _upload(hipmod, ix)
+    # (the adaptive choice lives in the device-pointer entry point; a host batch of this size goes through the chunked
+    # pipeline, which never runs an exploratory launch -- round 4)
+    import torch
+
+    dq = torch.from_numpy(Q).cuda()
+    od = torch.empty((len(Q), 10), dtype=torch.float32, device="cuda")
+    ol = torch.empty((len(Q), 10), dtype=torch.int32, device="cuda")
+    ond = torch.zeros(len(Q), dtype=torch.int64, device="cuda")
+
+    def launch(ef):
+        dev.search_device(dq.data_ptr(), len(Q), 10, ef, 100, od.data_ptr(), ol.data_ptr(), 0, ond.data_ptr())
+        torch.cuda.synchronize()
+        dev.status()
+        return dev.launch_info()
+
     # without tuning, the first big launches of a beam width are exploratory samples
-    dev.search(Q, 10, 64)
-    assert dev.launch_info()["exploratory"]
+    assert launch(64)["exploratory"]
     dev.set_option("sorted_beam", 2)  # resets what has been measured
     dev.tune(Q, 10, 64)
     finals = set()
     for _ in range(6):
-        got = dev.search(Q, 10, 64, stats=True)
-        info = dev.launch_info()
+        info = launch(64)
         assert not info["exploratory"]
         finals.add(info["variant_id"])
-        assert np.array_equal(want[1], got[1]) and np.array_equal(want[0].view(np.uint32), got[0].view(np.uint32))
-        assert np.array_equal(want[2]["n_dist"], got[2]["n_dist"])
+        assert np.array_equal(want[1], ol.cpu().numpy()) and np.array_equal(want[0].view(np.uint32), od.cpu().numpy().view(np.uint32))
+        assert np.array_equal(want[2]["n_dist"], ond.cpu().numpy().astype(np.uint64))
     assert len(finals) == 1  # the first launch after fnv_tune already runs the final variant, and so does every later one
     # another beam width has not been measured yet
-    dev.search(Q, 10, 40)
-    assert dev.launch_info()["exploratory"]
+    assert launch(40)["exploratory"]
     # device-resident queries
-    import torch
-
-    dq = torch.from_numpy(Q).cuda()
     dev.tune(int(dq.data_ptr()), 10, 40, nq=len(Q))
-    dev.search(Q, 10, 40)
+    assert not launch(40)["exploratory"]
+    dev.set_option("host_pipeline", 1)
+    dev.search(Q, 10, 28)  # a beam width nobody measured, through the chunked host pipeline: its launches never explore
     assert not dev.launch_info()["exploratory"]
+    dev.set_option("host_pipeline", 0)
     # every variant pinned: same bytes as the oracle
     slots = dev.launch_geometry()["blocks_per_cu"] * 256
-    for v in range(6):
+    for v in range(7):  # (6, round 4: the merged-beam kernel for every query + exact shadows of the last ones on idle slots)
         dev.set_option("sorted_variant", v)
         got = dev.search(Q, 10, 64, stats=True)
         info = dev.launch_info()
-        assert not info["exploratory"] and (info["variant_id"] == v or (v >= 2 and len(Q) <= slots))
+        assert not info["exploratory"] and (info["variant_id"] == v or (2 <= v <= 5 and len(Q) <= slots))
         assert np.array_equal(want[1], got[1]) and np.array_equal(want[0].view(np.uint32), got[0].view(np.uint32))
         assert all(np.array_equal(want[2][k], got[2][k]) for k in ("count", "n_dist", "n_hops"))
     with pytest.raises(ValueError):
-        dev.set_option("sorted_variant", 6)
+        dev.set_option("sorted_variant", 7)
     with pytest.raises(ValueError):
         dev.tune(Q[:0], 10, 64)
 

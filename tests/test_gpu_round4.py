@@ -56,7 +56,7 @@ def test_three_kilobyte_rows_keep_the_query_in_registers(oracle_mod, hipmod, dt,
         want = ix.search(Q, K, ef, stats=True)
         for name, opts in (("two_heaps", dict(sorted_beam=0)), ("merged_registers", dict(sorted_beam=1, beam_registers=1)),
                            ("merged_lds", dict(sorted_beam=1, beam_registers=0)), ("entry_kernel", dict(sorted_beam=1, entry_kernel=1))):
-            for k, v in dict(sorted_beam=2, beam_registers=1, entry_kernel=0, **opts).items():
+            for k, v in {**dict(sorted_beam=2, beam_registers=1, entry_kernel=0), **opts}.items():
                 dev.set_option(k, v)
             _assert_exact(want, dev.search(Q, K, ef, stats=True), "%s ef=%d" % (name, ef))
             lds[(name, ef)] = dev.launch_geometry()["lds_bytes"]
