@@ -222,9 +222,12 @@ struct IndexOptions {
 constexpr int kNumVariants = 7;
 constexpr int kVariantTailShadows = 6;
 static const int kTailPct[kNumVariants] = {0, 0, 50, 75, 100, 25, 0};
-static inline bool variant_allowed(int v, bool multi_round, bool try_tail, bool shadows_on) {
+static inline bool variant_allowed(int v, bool multi_round, bool try_tail, bool shadows_on, bool pinned_only = false) {
   if (v < 2) return true;
-  if (v == kVariantTailShadows) return shadows_on;
+  // (tail shadows: measured in round 4 -- within 1 % of the merged-beam kernel alone on every configuration, never the best:
+  //  a shadow can only start when a slot falls idle, which is too late for the ties that end a launch -- so the variant can
+  //  be pinned for A/B runs but is not part of the adaptive choice)
+  if (v == kVariantTailShadows) return shadows_on && pinned_only;
   return multi_round && try_tail;  // an exact tail needs more than one round of queries
 }
 
@@ -286,12 +289,9 @@ struct fnv_index_s : IndexOptions {
   // staging for the host-buffer entry point
   void* h_pin = nullptr;  // 1 MB of pinned host memory: staging of small host-buffer searches
   PinnedCall pin;
-  // Large host-buffer searches (round 4, search_host_pipelined): chunks of the batch alternate between this handle and an
-  // internal view of it (second workspace + stream), staged through pinned memory
-  fnv_index_s* pipe_view = nullptr;
-  void* h_pipe = nullptr;  // pinned: [queries of the batch][per-chunk result slabs]
+  // Large host-buffer searches (round 4, search_host_gated): pinned, GPU-mapped staging of a whole batch
+  void* h_pipe = nullptr;  // [gate word | status | queries of the batch | result slab]
   size_t h_pipe_bytes = 0;
-  std::vector<hipEvent_t> pipe_ev;  // one per chunk: its results have landed in h_pipe
   void* d_q = nullptr;
   size_t d_q_bytes = 0;
   void* d_out = nullptr;
@@ -574,11 +574,6 @@ int fnv_index_info(fnv_index_t ix, uint64_t info[8]) {
 
 int fnv_index_free(fnv_index_t ix) {
   if (!ix) return FNV_OK;
-  if (ix->pipe_view) {  // the internal view of the pipelined host path goes first (it counts as a view of this handle)
-    fnv_index_s* v = ix->pipe_view;
-    ix->pipe_view = nullptr;
-    (void)fnv_index_free(v);
-  }
   if (ix->n_views.load() > 0)
     return fail(FNV_ERR_INVALID, "fnv_index_free: the index still has live views (fnv_index_view) on its buffers; free them first");
   DeviceScope scope(ix->device);
@@ -590,7 +585,6 @@ int fnv_index_free(fnv_index_t ix) {
     if (b) (void)hipFree(b);
   if (ix->h_pin) (void)hipHostFree(ix->h_pin);
   if (ix->h_pipe) (void)hipHostFree(ix->h_pipe);
-  for (hipEvent_t e : ix->pipe_ev) (void)hipEventDestroy(e);
   if (ix->ev0) (void)hipEventDestroy(ix->ev0);
   if (ix->ev1) (void)hipEventDestroy(ix->ev1);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -704,7 +698,7 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
 static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq, int K, int ef_search,
                               int num_initializations, float* d_out_dist, int32_t* d_out_labels, int32_t* d_out_count,
                               uint64_t* d_out_ndist, uint64_t* d_out_nhops, void* hip_stream, bool node_ids,
-                              int force_variant = -1);
+                              int force_variant = -1, const uint32_t* gate = nullptr);
 
 int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, int K, int ef_search,
                             int num_initializations, float* d_out_dist, int32_t* d_out_labels,
@@ -861,8 +855,9 @@ static int grow(void** buf, size_t* have, size_t need, bool zero = false) {
 static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq, int K, int ef_search,
                               int num_initializations, float* d_out_dist, int32_t* d_out_labels, int32_t* d_out_count,
                               uint64_t* d_out_ndist, uint64_t* d_out_nhops, void* hip_stream, bool node_ids,
-                              int force_variant) {  // force_variant >= 0: fnv_tune's launches (an argument, not index state:
-                                                    // a concurrent caller's launch on the same handle is never forced)
+                              int force_variant,    // >= 0: fnv_tune's launches (an argument, not index state: a concurrent
+                                                    // caller's launch on the same handle is never forced)
+                              const uint32_t* gate) {  // non-null: queries [0, *gate) have been staged (search_host_gated)
   if (!ix) return fail(FNV_ERR_INVALID, "index is null");
   // Index.h:847-849
   if (num_initializations <= 0) return fail(FNV_ERR_INVALID, "num_initializations must be greater than 0.");
@@ -985,7 +980,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   const bool shadows_on = ix->shadow_exact != 0;
   const bool try_tail = ix->sorted_tail_exact_pct < 0;
   if (sorted && pinned >= 0) {
-    variant = variant_allowed(pinned, multi_round, true, shadows_on) ? pinned : 1;
+    variant = variant_allowed(pinned, multi_round, true, shadows_on, true) ? pinned : 1;
     sorted = variant != 0;
     if (variant >= 2) tail_pct = kTailPct[variant];
   } else if (sorted && ix->sorted_beam == 2) {
@@ -1062,6 +1057,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   p.status = (int32_t*)(ix->d_dispenser + 1);
   p.redo_count = ix->d_dispenser + 3;  // [3] queries searched exactly after a tie, [4..7] by reason
   p.phase_cycles = ix->d_phase;
+  p.gate = gate;
   p.tail_exact = multi_round && sorted ? (uint32_t)std::min<uint64_t>((uint64_t)tail_pct * nslots / 100, nq) : 0u;
 
   HIP_TRY(hipMemsetAsync(ix->d_dispenser, 0, 8 * sizeof(uint32_t), stream));
@@ -1230,146 +1226,72 @@ static int check_search_args(fnv_index_t ix, const void* queries, uint64_t nq, i
 // Large host-buffer searches (SURVEY.md 8d defines the metric on the batched call INCLUDING the H2D of the queries and
 // the D2H of the results; reference: bindings.cpp:161-228 hands host arrays in and out).  Round 3 sent the whole batch
 // through one pageable hipMemcpyAsync (which blocks its caller while the runtime stages it), one launch and five pageable
-// copies back: 0.75-0.92 of the device-resident rate.  Now the batch is cut into chunks -- 512, 1024, 2048, then 4096
-// queries -- and each chunk is staged by the CPU into pinned memory, copied, searched and copied back on its own, chunks
-// alternating between this handle's stream and an internal view's (two launches in flight: the next chunk's queries start
-// on the slots the previous chunk's stragglers leave idle), so the GPU starts after the first 512 queries have been staged
-// (~30 us) and staging, copies and searches of later chunks overlap; results are scattered to the caller's arrays as each
-// chunk's event completes.  Same bytes as one launch: queries are independent, a chunk is a batch.
-// When the tuned choice for this beam width says equal keys make last-round re-runs expensive (a tail variant), the
-// last chunk is kept small and searched by the exact two-heap kernel alone.
-static int search_host_pipelined(fnv_index_t ix, const void* queries, uint64_t nq, int K, int ef_search, int num_initializations,
-                                 float* out_dist, int32_t* out_labels, int32_t* out_count, uint64_t* out_ndist,
-                                 uint64_t* out_nhops) {
+// copies back: 0.75-0.92 of the device-resident rate.  Round 4, first attempt (measured, replaced): the batch cut into
+// chunks of 512 ... 4096 queries, each its own copy + launch + copy on alternating streams -- every chunk paid a whole
+// query latency plus its own stragglers and the launches hardly overlapped: 2.4-3.3 ms where the single launch takes
+// 1.28.  What is built instead keeps ONE launch and lets the queries arrive underneath it, with no copy at all:
+//   * the batch is staged by the CPU into PINNED host memory that the GPU reads directly (a query is read once, 512 bytes
+//     over PCIe at the start of a search that lasts hundreds of microseconds; 10 000 queries per millisecond are 5 GB/s);
+//   * the kernel is launched FIRST, with a gate (SearchParams::gate) in the same pinned buffer: its dispenser hands query i
+//     out as usual, and the wave that got it waits until the gate word says that more than i queries have been staged; the
+//     CPU stages in pieces (256, 512, 1024 ... 4096 queries) and moves the gate after each, so the first searches start
+//     tens of microseconds into the call and the rest of the staging hides under them;
+//   * results are written by the kernel straight into the pinned buffer and scattered to the caller's arrays when the
+//     stream has drained: no device-side staging of queries or results, no copy engine, three API calls per search.
+// Same bytes as the plain path ("host_pipeline" = 0): the gate only delays when a query starts.
+static int search_host_gated(fnv_index_t ix, const void* queries, uint64_t nq, int K, int ef_search, int num_initializations,
+                             float* out_dist, int32_t* out_labels, int32_t* out_count, uint64_t* out_ndist,
+                             uint64_t* out_nhops) {
   ON_DEVICE(ix->device);
   const size_t qrow = (size_t)ix->dim * dtype_size(ix->dtype);
-  const size_t orow = (size_t)K * 8 + 4 + 8 + 8;  // per query: K distances, K labels, count, n_dist, n_hops
-  auto slab_bytes = [&](uint64_t n) { return ((size_t)n * orow + 8 + 63) & ~(size_t)63; };  // (+8: the counters start 8-byte aligned)
-  // ---- the variant every chunk runs: never an exploratory one inside a caller's search
-  const int B = std::max(ef_search, K);
-  int chunk_variant = 1, tuned = -1;
-  {
-    std::lock_guard<std::mutex> lock(ix->mu);
-    for (int key : {2 * B + 1, 2 * B}) {
-      auto it = ix->tuner.find(key);
-      if (it == ix->tuner.end() || it->second.samples[0] == 0 || it->second.samples[1] == 0) continue;
-      const fnv_index_s::Tuner& t = it->second;
-      int best = 0;
-      for (int v = 1; v < kNumVariants; v++)
-        if (t.samples[v] > 0 && t.best[v] < t.best[best]) best = v;
-      tuned = best;
-      chunk_variant = best == 0 ? 0 : 1;
-      break;
-    }
-    if (ix->sorted_variant >= 0) chunk_variant = ix->sorted_variant == 0 ? 0 : 1, tuned = (int)ix->sorted_variant;
-  }
-  const bool exact_last = tuned >= 2 && tuned != kVariantTailShadows;
-  const bool shadow_last = tuned == kVariantTailShadows;  // the last chunk gets exact shadows on the slots its drain leaves idle
-  // ---- chunk plan
-  std::vector<uint64_t> lo, cnt;
-  {
-    uint64_t done = 0, size = 512;
-    while (done < nq) {
-      uint64_t n = std::min<uint64_t>(size, nq - done);
-      if (exact_last && nq - done > 1024 && nq - done - n < 1024) n = nq - done - 1024;  // leave a last chunk of 1024
-      lo.push_back(done);
-      cnt.push_back(n);
-      done += n;
-      if (size < 4096) size *= 2;
-    }
-  }
-  const size_t nchunk = lo.size();
-  size_t slabs = 0;
-  std::vector<size_t> slab_off(nchunk);
-  for (size_t c = 0; c < nchunk; c++) {
-    slab_off[c] = slabs;
-    slabs += slab_bytes(cnt[c]);
-  }
   const size_t qbytes = ((size_t)nq * qrow + 63) & ~(size_t)63;
+  // one output slab: dist | labels | count | ndist | nhops
+  const size_t o_lab = (size_t)nq * K * 4;
+  const size_t o_cnt = o_lab + (size_t)nq * K * 4;
+  const size_t o_nd = (o_cnt + (size_t)nq * 4 + 7) & ~(size_t)7;
+  const size_t o_nh = o_nd + (size_t)nq * 8;
+  const size_t obytes = (o_nh + (size_t)nq * 8 + 63) & ~(size_t)63;
   {
     std::lock_guard<std::mutex> lock(ix->mu);
-    int rc = grow(&ix->d_q, &ix->d_q_bytes, qbytes);
-    if (!rc) rc = grow(&ix->d_out, &ix->d_out_bytes, slabs);
-    if (rc) return rc;
-    if (qbytes + slabs > ix->h_pipe_bytes) {
+    const size_t need = 128 + qbytes + obytes;
+    if (need > ix->h_pipe_bytes) {
       if (ix->h_pipe) HIP_TRY(hipHostFree(ix->h_pipe));
       ix->h_pipe = nullptr;
       ix->h_pipe_bytes = 0;
-      HIP_TRY(hipHostMalloc(&ix->h_pipe, qbytes + slabs, hipHostMallocDefault));
-      ix->h_pipe_bytes = qbytes + slabs;
-    }
-    while (ix->pipe_ev.size() < nchunk) {
-      hipEvent_t e;
-      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      ix->pipe_ev.push_back(e);
+      // mapped into every device's address space: the GPU reads / writes it directly
+      HIP_TRY(hipHostMalloc(&ix->h_pipe, need + need / 4, hipHostMallocPortable | hipHostMallocMapped));
+      ix->h_pipe_bytes = need + need / 4;
     }
   }
-  if (!ix->pipe_view) {
-    fnv_index_t v = nullptr;
-    int rc = fnv_index_view(ix, &v);
-    if (rc) return rc;
-    ix->pipe_view = v;
-  }
-  fnv_index_s* view = ix->pipe_view;
-  {  // the view answers exactly like its source: same options, same measured layouts
-    std::lock_guard<std::mutex> l1(ix->mu);
-    std::lock_guard<std::mutex> l2(view->mu);
-    if (view->options_version != ix->options_version || view->layouts.size() != ix->layouts.size()) {
-      static_cast<IndexOptions&>(*view) = static_cast<const IndexOptions&>(*ix);
-      view->layouts = ix->layouts;
-      view->options_version = ix->options_version;
-      view->plan.valid = false;
-    }
-  }
-  uint8_t* hq = (uint8_t*)ix->h_pipe;
+  uint32_t* gate = (uint32_t*)ix->h_pipe;                 // [0] queries staged so far (own 64-byte line)
+  int32_t* hstatus = (int32_t*)((uint8_t*)ix->h_pipe + 64);
+  uint8_t* hq = (uint8_t*)ix->h_pipe + 128;
   uint8_t* ho = hq + qbytes;
-  uint8_t* dq = (uint8_t*)ix->d_q;
-  uint8_t* dout = (uint8_t*)ix->d_out;
-  fnv_index_s* handles[2] = {ix, view};
-  bool first = true;
-  for (size_t c = 0; c < nchunk; c++) {
-    fnv_index_s* h = handles[c & 1];
-    const uint64_t n = cnt[c];
-    memcpy(hq + lo[c] * qrow, (const uint8_t*)queries + lo[c] * qrow, n * qrow);
-    HIP_TRY(hipMemcpyAsync(dq + lo[c] * qrow, hq + lo[c] * qrow, n * qrow, hipMemcpyHostToDevice, h->stream));
-    uint8_t* o = dout + slab_off[c];
-    float* od = (float*)o;
-    int32_t* ol = (int32_t*)(o + n * K * 4);
-    int32_t* oc = (int32_t*)(o + n * K * 8);
-    uint64_t* ond = (uint64_t*)(o + ((n * K * 8 + n * 4 + 7) & ~(size_t)7));
-    uint64_t* onh = ond + n;
-    const int variant = (c + 1 == nchunk && nchunk > 1) ? (exact_last ? 0 : shadow_last ? kVariantTailShadows : chunk_variant) : chunk_variant;
-    int rc = search_device_impl(h, dq + lo[c] * qrow, n, K, ef_search, num_initializations, od, ol, oc, ond, onh, h->stream,
-                                ix->output_node_ids != 0, variant);
-    if (rc) {
-      for (fnv_index_s* hh : handles) (void)hipStreamSynchronize(hh->stream);
-      return rc;
-    }
-    if (first) ix->t_enqueue_ns = now_ns();
-    first = false;
-    HIP_TRY(hipMemcpyAsync(ho + slab_off[c], o, (size_t)((uint8_t*)(onh + n) - o), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipEventRecord(ix->pipe_ev[c], h->stream));
+  __atomic_store_n(gate, 0u, __ATOMIC_RELEASE);            // closed (the previous call has drained: host_mu is held)
+  int rc = search_device_impl(ix, hq, nq, K, ef_search, num_initializations, (float*)ho, (int32_t*)(ho + o_lab),
+                              (int32_t*)(ho + o_cnt), (uint64_t*)(ho + o_nd), (uint64_t*)(ho + o_nh), ix->stream,
+                              ix->output_node_ids != 0, -1, gate);
+  if (rc) return rc;  // nothing was launched
+  ix->t_enqueue_ns = now_ns();
+  HIP_TRY(hipMemcpyAsync(hstatus, ix->d_dispenser + 1, sizeof(int32_t), hipMemcpyDeviceToHost, ix->stream));
+  // the queries arrive underneath the running kernel
+  for (uint64_t done = 0, size = 256; done < nq; size = std::min<uint64_t>(size * 2, 4096)) {
+    const uint64_t n = std::min<uint64_t>(size, nq - done);
+    memcpy(hq + done * qrow, (const uint8_t*)queries + done * qrow, n * qrow);
+    done += n;
+    __atomic_store_n(gate, (uint32_t)done, __ATOMIC_RELEASE);
   }
-  int status = ST_OK;
-  for (size_t c = 0; c < nchunk; c++) {
-    HIP_TRY(hipEventSynchronize(ix->pipe_ev[c]));
-    const uint64_t n = cnt[c];
-    const uint8_t* o = ho + slab_off[c];
-    memcpy(out_dist + lo[c] * K, o, n * K * 4);
-    memcpy(out_labels + lo[c] * K, o + n * K * 4, n * K * 4);
-    if (out_count) memcpy(out_count + lo[c], o + n * K * 8, n * 4);
-    const uint8_t* ond = o + ((n * K * 8 + n * 4 + 7) & ~(size_t)7);
-    if (out_ndist) memcpy(out_ndist + lo[c], ond, n * 8);
-    if (out_nhops) memcpy(out_nhops + lo[c], ond + n * 8, n * 8);
-  }
+  HIP_TRY(hipStreamSynchronize(ix->stream));
   ix->t_complete_ns = now_ns();
-  for (fnv_index_s* h : handles) {  // the sticky status word of either workspace
-    int32_t st = 0;
-    HIP_TRY(hipMemcpy(&st, h->d_dispenser + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (st != ST_OK) status = st;
-  }
-  if (status == ST_CAND_OVERFLOW)
+  memcpy(out_dist, ho, (size_t)nq * K * 4);
+  memcpy(out_labels, ho + o_lab, (size_t)nq * K * 4);
+  if (out_count) memcpy(out_count, ho + o_cnt, (size_t)nq * 4);
+  if (out_ndist) memcpy(out_ndist, ho + o_nd, (size_t)nq * 8);
+  if (out_nhops) memcpy(out_nhops, ho + o_nh, (size_t)nq * 8);
+  if (*hstatus == ST_CAND_OVERFLOW)
     return fail(FNV_ERR_CAPACITY, "candidate heap overflowed its HBM spill area; raise the spill_entries option");
+  if (*hstatus == ST_GATE_TIMEOUT)
+    return fail(FNV_ERR_RUNTIME, "host-buffer search: the kernel gave up waiting for its queries");
   return FNV_OK;
 }
 
@@ -1380,13 +1302,13 @@ int fnv_search_batch(fnv_index_t ix, const void* queries, uint64_t nq, int K, in
   if (rc || nq == 0) return rc;
   std::lock_guard<std::mutex> host_lock(ix->host_mu);  // concurrent callers share one staging area: serialise
   {
-    // batches that do not fit the 1 MB pinned buffer of the small-batch path go through the chunked pipeline
+    // batches that do not fit the 1 MB pinned buffer of the small-batch path: one gated launch, queries arriving under it
     const size_t qbytes = (size_t)nq * ix->dim * dtype_size(ix->dtype);
     const size_t obytes = (size_t)nq * ((size_t)K * 8 + 4 + 8 + 8) + 64;
     const bool small = ((qbytes + 63) & ~(size_t)63) + ((obytes + 63) & ~(size_t)63) + 128 <= (1u << 20);
-    if (!small && nq >= 1024 && !ix->parent && ix->host_pipeline != 0)  // (a view has no view of its own: it takes the plain path)
-      return search_host_pipelined(ix, queries, nq, K, ef_search, num_initializations, out_dist, out_labels, out_count, out_ndist,
-                                   out_nhops);
+    if (!small && nq >= 1024 && ix->host_pipeline != 0 && !ix->entry_kernel)  // (the batched entry scan reads every query up front)
+      return search_host_gated(ix, queries, nq, K, ef_search, num_initializations, out_dist, out_labels, out_count, out_ndist,
+                               out_nhops);
   }
   rc = search_host_enqueue(ix, queries, nq, K, ef_search, num_initializations, out_dist, out_labels, out_count,
                            out_ndist, out_nhops);
@@ -1650,13 +1572,10 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
     if (r) return r;
     const bool multi = nq > (uint64_t)ix->plan.sbpc * (uint64_t)ix->num_cus;
     if (multi && ix->sorted_tail_exact_pct < 0 && (r = time_variant(3, 4, &t4)) != FNV_OK) return r;
-    float t6 = -1.f;
-    if (ix->shadow_exact != 0 && (r = time_variant(kVariantTailShadows, 4, &t6)) != FNV_OK) return r;
     *out = (t4 > 0.f && t4 < t1) ? t4 : t1;
-    if (t6 > 0.f && t6 < *out) *out = t6;
     if (tune_log)
-      fprintf(stderr, "fnv_tune B=%d layout %zu (heap in LDS %d, table %u): merged %.4f ms, 75%% tail exact %.4f ms, tail shadows %.4f ms -> %u slots, %d per CU\n", B,
-              li, (int)cands[li].cand_lds, cands[li].vis_slots, t1 * (float)nq, t4 * (float)nq, t6 * (float)nq, (unsigned)ix->geom[4], (int)ix->geom[3]);
+      fprintf(stderr, "fnv_tune B=%d layout %zu (heap in LDS %d, table %u): merged %.4f ms, 75%% tail exact %.4f ms -> %u slots, %d per CU\n", B,
+              li, (int)cands[li].cand_lds, cands[li].vis_slots, t1 * (float)nq, t4 * (float)nq, (unsigned)ix->geom[4], (int)ix->geom[3]);
     return FNV_OK;
   };
   // The device settles first.  After the GPU has idled (the caller computed something on the host) the first launches run

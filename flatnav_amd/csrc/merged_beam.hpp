@@ -109,14 +109,21 @@ __device__ __forceinline__ float lane_of(const float (&a)[R], int r, int l) {
 }
 
 template <typename T, int METRIC, int G, int CU, bool FULL, int R>
-__global__ __launch_bounds__(WAVE, CU == 1 ? 5 : waves_per_simd<G>(FNV_SORTED_WAVES_PER_SIMD)) void beam_search_merged_kernel(const SearchParams p) {
-  // (128-byte rows: 97 registers as compiled for four waves per SIMD -- one over the budget of five, which they fit)
+__global__ __launch_bounds__(WAVE, CU == 1 ? 5 : R == MB_R ? 3 : waves_per_simd<G>(FNV_SORTED_WAVES_PER_SIMD)) void beam_search_merged_kernel(const SearchParams p) {
+  // (128-byte rows: 97 registers as compiled for four waves per SIMD -- one over the budget of five, which they fit.
+  //  The four-chunk form -- beams of 129-256 entries -- is compiled for THREE waves per SIMD (168 registers, round 4): its
+  //  LDS footprint, a 6144-slot table next to the beam, keeps at most 9-11 queries per CU resident anyway, and at four
+  //  waves it kept 4-8 registers of the merge in scratch memory)
   constexpr int PU = passes<G, CU>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x;
+  const int lane_of_kernel = threadIdx.x;
   const float INF = std::numeric_limits<float>::infinity();
 
   while (true) {
+    // (opaque per query, like the tail's below: lane-derived constants of the prologue are computed per query, not kept
+    // alive -- in scratch, in the four-chunk form -- from the kernel's entry on)
+    int lane = lane_of_kernel;
+    asm volatile("" : "+v"(lane));
     const int item = next_query(lane);
     if (item < 0) break;
     // shadows (search_params.h): items >= shadow_base are exact searches of the LAST queries, most recent first

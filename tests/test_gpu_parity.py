@@ -35,12 +35,8 @@ def _build(oracle_mod, metric, dt, X, M, efc=100):
 
 
 def _upload(hipmod, ix):
-    dev = hipmod.DeviceIndex.upload(ix.blob(), ix.node_size, ix.data_size, ix.M, ix.cur_nodes, ix.dtype,
-                                    ix.metric, ix.dim)
-    # this file is about the kernels: one host batch = ONE launch whose geometry the tests look at (the chunked host
-    # pipeline of round 4 has its own tests in test_gpu_round4.py)
-    dev.set_option("host_pipeline", 0)
-    return dev
+    return hipmod.DeviceIndex.upload(ix.blob(), ix.node_size, ix.data_size, ix.M, ix.cur_nodes, ix.dtype,
+                                     ix.metric, ix.dim)
 
 
 def _assert_exact(o, g):

@@ -25,9 +25,7 @@ def hipmod():
 
 
 def _upload(hipmod, ix):
-    dev = hipmod.DeviceIndex.upload(ix.blob(), ix.node_size, ix.data_size, ix.M, ix.cur_nodes, ix.dtype, ix.metric, ix.dim)
-    dev.set_option("host_pipeline", 0)  # one host batch = one launch (the chunked pipeline is test_gpu_round4.py's subject)
-    return dev
+    return hipmod.DeviceIndex.upload(ix.blob(), ix.node_size, ix.data_size, ix.M, ix.cur_nodes, ix.dtype, ix.metric, ix.dim)
 
 
 @pytest.mark.parametrize("dt,dim,metric", [("float32", 100, "angular"), ("uint8", 100, "l2"), ("float32", 200, "l2"),
@@ -102,8 +100,6 @@ def test_tune_settles_the_kernel_choice_and_variants_can_be_pinned(oracle_mod, h
     ix.add(X, 64)
     want = ix.search(Q, 10, 64, stats=True)
     dev = _upload(hipmod, ix)
-    # (the adaptive choice lives in the device-pointer entry point; a host batch of this size goes through the chunked
-    # pipeline, which never runs an exploratory launch -- round 4)
     import torch
 
     dq = torch.from_numpy(Q).cuda()
@@ -134,10 +130,8 @@ def test_tune_settles_the_kernel_choice_and_variants_can_be_pinned(oracle_mod, h
     # device-resident queries
     dev.tune(int(dq.data_ptr()), 10, 40, nq=len(Q))
     assert not launch(40)["exploratory"]
-    dev.set_option("host_pipeline", 1)
-    dev.search(Q, 10, 28)  # a beam width nobody measured, through the chunked host pipeline: its launches never explore
+    dev.search(Q, 10, 40)  # the host-buffer entry point launches the same way
     assert not dev.launch_info()["exploratory"]
-    dev.set_option("host_pipeline", 0)
     # every variant pinned: same bytes as the oracle
     slots = dev.launch_geometry()["blocks_per_cu"] * 256
     for v in range(7):  # (6, round 4: the merged-beam kernel for every query + exact shadows of the last ones on idle slots)

@@ -1,8 +1,8 @@
 """Round 4 on the GPU, all through the C ABI and against the CPU oracle (bit-exact on integer-valued data):
   * rows of exactly 3 KB keep their query in registers (csrc/distance.hpp `query_in_regs`): every kernel form, every element
     type, a dimension that leaves the last chunk partly empty;
-  * large host-buffer searches run as a chunked pinned pipeline over two streams (`search_host_pipelined`): the bytes of one
-    launch, whatever the chunk plan (odd sizes, an exact last chunk after fnv_tune, pinned variants);
+  * large host-buffer searches are one launch that starts before its queries are staged (`search_host_gated`: queries read
+    from pinned host memory behind a gate word, results written straight back): the plain path's bytes, whatever the batch;
   * `fnv_index_adopt`: a handle on buffers somebody else owns;
   * options that cannot change the launch plan leave fnv_tune's result alone."""
 import numpy as np
@@ -72,49 +72,64 @@ def test_three_kilobyte_rows_keep_the_query_in_registers(oracle_mod, hipmod, dt,
     # the device builder's kernels read their staged vectors into the same registers: sequential insertion = the oracle's graph
     import flatnav_amd as flatnav
 
-    if dt == "float32":
-        index = flatnav.index.create(metric, dim, 600, 16)
-        index.add(X[:100], 48)
-        for i in range(100, 600, 1):
-            index.add(X[i:i + 1], 48, device=True)
-        small = oracle_mod.OracleIndex.create(metric, dim, 600, 16, dt)
-        small.add(X[:600], 48)
-        assert np.array_equal(np.asarray(index._raw_blob()).reshape(-1)[: 600 * small.node_size], small.blob()[: 600 * small.node_size])
+    index = flatnav.index.create(metric, dim, 600, 16, getattr(flatnav.data_type.DataType, dt))
+    index.add(X[:600], 48, device=True, device_max_batch=1, device_bootstrap=40)  # one node per device batch = Index::add
+    small = oracle_mod.OracleIndex.create(metric, dim, 600, 16, dt)
+    small.add(X[:600], 48)
+    want_g = np.asarray(small.blob())[: 600 * small.node_size].reshape(600, small.node_size)
+    got_g = np.asarray(index._raw_blob())[: 600 * small.node_size].reshape(600, small.node_size)
+    bad = np.flatnonzero((want_g != got_g).any(axis=1))
+    assert bad.size == 0, "first differing node %d of %d differing" % (bad[0], bad.size)
 
 
 @pytest.mark.parametrize("dt", ["float32", "uint8"])
-def test_pipelined_host_search_returns_the_single_launch_bytes(oracle_mod, hipmod, dt):
-    # Host-buffer batches above the 1 MB pinned buffer go out in chunks of 512, 1024, 2048, 4096 ... queries alternating
-    # over two streams.  Whatever the chunk plan -- odd sizes, one query more than a chunk boundary, the small exact last
-    # chunk that a tuned tail variant asks for, a pinned variant -- ids, distances, counts and counters are the oracle's,
-    # null output arrays are left alone, and the caller's arrays are only written inside [0, nq).
-    X, Q = ds.sift_like(20000, 12000)
+def test_gated_host_search_returns_the_plain_paths_bytes(oracle_mod, hipmod, dt):
+    # Host-buffer batches above the 1 MB pinned buffer: ONE launch that starts before its queries are staged -- the kernel
+    # reads them from pinned host memory, a gate word tells it how far the CPU has got (256, 512, 1024 ... queries at a
+    # time), results are written straight back into the pinned buffer.  Whatever the batch size (one query past a piece
+    # boundary, odd sizes), the kernel variant (tuned: an exact tail; pinned ones, tail shadows included) or the beam
+    # width, ids, distances, counts and counters are the oracle's; consecutive calls with DIFFERENT queries never see each
+    # other's data; null output arrays are left alone.
+    X, Q = ds.sift_like(20000, 24000)
     X, Q = X.astype(dt), Q.astype(dt)
+    Qa, Qb = Q[:12000], Q[12000:]
     ix = oracle_mod.OracleIndex.create("l2", 128, 20000, 16, dt)
     ix.add(X, 48)
     dev = _upload(hipmod, ix)
     K, ef = 10, 64
-    want = ix.search(Q, K, ef, stats=True, threads=8)
+    want_a = ix.search(Qa, K, ef, stats=True, threads=8)
+    want_b = ix.search(Qb, K, ef, stats=True, threads=8)
+
+    def cut(w, n):
+        return tuple(x[:n] if not isinstance(x, dict) else {k: v[:n] for k, v in x.items()} for x in w)
+
     for nq in (12000, 3585, 3584, 2049, 7681, 1024 if dt == "uint8" else 2100):
-        got = dev.search(Q[:nq], K, ef, stats=True)
-        _assert_exact(tuple(w[:nq] if not isinstance(w, dict) else {k: v[:nq] for k, v in w.items()} for w in want), got, "nq=%d" % nq)
-    # after fnv_tune (integer-valued data: a tail variant wins, so the last chunk is 1024 queries of the two-heap kernel)
-    dev.tune(Q[:10000], K, ef)
-    tuned = dev.search(Q, K, ef, stats=True)
-    _assert_exact(want, tuned, "tuned")
-    for variant in (0, 1, 3):
+        _assert_exact(cut(want_a, nq), dev.search(Qa[:nq], K, ef, stats=True), "nq=%d" % nq)
+        _assert_exact(cut(want_b, nq), dev.search(Qb[:nq], K, ef, stats=True), "other queries, nq=%d" % nq)
+    d_only, l_only = dev.search(Qa[:5000], K, ef)  # no count / counter arrays
+    assert np.array_equal(l_only, want_a[1][:5000]) and np.array_equal(d_only.view(np.uint32), want_a[0][:5000].view(np.uint32))
+    # after fnv_tune (integer-valued data: a tail variant wins)
+    dev.tune(Qa[:10000], K, ef)
+    _assert_exact(want_a, dev.search(Qa, K, ef, stats=True), "tuned")
+    for variant in (0, 1, 3, 6):
         dev.set_option("sorted_variant", variant)
-        _assert_exact(want, dev.search(Q, K, ef, stats=True), "variant %d" % variant)
+        _assert_exact(want_b, dev.search(Qb, K, ef, stats=True), "variant %d" % variant)
+        _assert_exact(want_a, dev.search(Qa, K, ef, stats=True), "variant %d" % variant)
     dev.set_option("sorted_variant", -1)
-    # a view of the handle (no pipeline of its own) and the handle itself agree; closing order is free of surprises
+    # the plain path gives the same bytes, and so does a view of the handle
+    dev.set_option("host_pipeline", 0)
+    _assert_exact(want_b, dev.search(Qb, K, ef, stats=True), "plain path")
+    dev.set_option("host_pipeline", 1)
     view = dev.view()
-    _assert_exact(want, view.search(Q, K, ef, stats=True), "view")
+    _assert_exact(want_a, view.search(Qa, K, ef, stats=True), "view")
     view.close()
-    _assert_exact(want, dev.search(Q, K, ef, stats=True), "after the view")
-    # wide beams through the same path (LDS form of the merged-beam kernel, spills of the visited set)
+    _assert_exact(want_b, dev.search(Qb, K, ef, stats=True), "after the view")
+    # wide beams through the same path (LDS form of the merged-beam kernel, spills of the visited set), two-heap kernel
     dev.set_option("visited_slots", 512)
-    w2 = ix.search(Q[:3000], 5, 300, stats=True, threads=8)
-    _assert_exact(w2, dev.search(Q[:3000], 5, 300, stats=True), "ef=300")
+    w2 = ix.search(Qa[:3000], 5, 300, stats=True, threads=8)
+    _assert_exact(w2, dev.search(Qa[:3000], 5, 300, stats=True), "ef=300")
+    dev.set_option("sorted_beam", 0)
+    _assert_exact(w2, dev.search(Qa[:3000], 5, 300, stats=True), "ef=300, two heaps")
 
 
 def test_adopted_buffers_answer_like_their_owner(oracle_mod, hipmod):
