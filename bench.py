@@ -381,6 +381,21 @@ def run_config(ctx, args, config, main_line):
     for o in args.opt:
         k, v = o.split("=")
         dev.set_option(k, int(v))
+    # Every NQ-query search this function asks for is counted, so that a kernel trace of this process can find the timed
+    # region by position from the END of its full-grid launches (fnv_tune's own launches all come before it):
+    # `roofline.trace_position` = {timed: launches of the timed region, after: launches that followed it}.
+    launches = {"n": 0, "timed_end": 0}
+    _sd, _sh = dev.search_device, dev.search
+
+    def _count_device(*a, **k):
+        launches["n"] += 1
+        return _sd(*a, **k)
+
+    def _count_host(*a, **k):
+        launches["n"] += 1
+        return _sh(*a, **k)
+
+    dev.search_device, dev.search = _count_device, _count_host
     ROW = dev.row_bytes  # bytes one row occupies in HBM (>= DIM * ESIZE: 16-byte chunks, whole 128-byte lines when cheap)
     # bytes of the 128-byte lines one row touches: the stride itself when rows are whole lines, else the expectation for
     # a row that starts at a random 16-byte boundary inside a line
@@ -487,6 +502,8 @@ def run_config(ctx, args, config, main_line):
                 break
         barrier()
         elapsed = time.perf_counter() - t0
+        if launches["timed_end"] is None:
+            launches["timed_end"] = launches["n"]  # (the main measurement's timed region ends here)
         dev.status()
         per_rank.clear()
         if dist is not None:
@@ -523,6 +540,7 @@ def run_config(ctx, args, config, main_line):
         return dict(elapsed=elapsed, steps=done, qps=NQ * world * done / elapsed, bytes=byts, row_bytes=row_byts, nd=nd_mean,
                     nh=nh_mean, kernel_ms=avg_kernel_s * 1e3, achieved=byts / avg_kernel_s / 1e9, explored=explored)
 
+    launches["timed_end"] = None
     main_m = measure(EF, args.steps, args.warmup)
     main_per_rank = list(per_rank)
     out = None
@@ -668,6 +686,7 @@ def run_config(ctx, args, config, main_line):
                 "line_bytes_per_launch": main_m["row_bytes"],
                 "achieved_line_GBps": main_m["row_bytes"] / (main_m["kernel_ms"] / 1e3) / 1e9,
                 "avg_kernel_ms": main_m["kernel_ms"],
+                "trace_position": {"timed": args.steps, "after": None},  # filled in below, once every launch has been made
             },
             "secondary": secondary,
             "sustained": sustained,
@@ -684,7 +703,10 @@ def run_config(ctx, args, config, main_line):
             out["cpu_baseline"] = cpu_baseline(index, dev, Q_rank[0], K, EF, hw, DT, metric, seconds=8.0 if main_line else 5.0)
             if not main_line:  # (the host is described once, in the main line's sample)
                 out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"].split("; host:")[0]
+    if out is not None:
+        out["roofline"]["trace_position"]["after"] = launches["n"] - launches["timed_end"]
     # ---- give everything back before the next configuration ----------------------------------------------------------
+    dev.search_device, dev.search = _sd, _sh
     dev.close()
     del dev, index, dq, d_dist, d_lab, d_cnt, d_nd, d_nh, gts, data, Q_all, Q_rank
     gc.collect()
@@ -734,7 +756,8 @@ def recorded_traffic(config, dtype, n, nq, ef):
     """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate runs, corrected as MI355X_MICROARCH.md prescribes) -- a RECORDED number, labelled as such; None unless
     the committed passes profiled this very workload."""
-    for name in ("r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "pmc_hbm_traffic.json"):
+    config = config.replace("-uint8", "")  # (the uint8 index is recorded as config c2, dtype uint8)
+    for name in ("r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "pmc_hbm_traffic.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):

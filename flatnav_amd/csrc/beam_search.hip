@@ -212,7 +212,7 @@ struct IndexOptions {
           cand_slots = 0, spill_entries = 16384, blocks_per_cu = 0, visited_wide = 0,
           entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0, sorted_beam = 2,
           sorted_beam_min = 1, sorted_cand_lds = 2, sorted_tail_exact_pct = -1, beam_registers = 1,
-          sorted_variant = -1, tune_layout = 1, shadow_exact = 1, host_pipeline = 1;
+          sorted_variant = -1, tune_layout = 1, shadow_exact = 1;
   int64_t overflow_list = -1;  // -1: automatic (a list in HBM only when the bitmap is larger than 512 KB)
 };
 
@@ -288,10 +288,9 @@ struct fnv_index_s : IndexOptions {
   size_t done_bytes = 0;
   // staging for the host-buffer entry point
   void* h_pin = nullptr;  // 1 MB of pinned host memory: staging of small host-buffer searches
+  void* h_res = nullptr;  // pinned host memory for the result slab of larger host-buffer searches (grown on demand)
+  size_t h_res_bytes = 0;
   PinnedCall pin;
-  // Large host-buffer searches (round 4, search_host_gated): pinned, GPU-mapped staging of a whole batch
-  void* h_pipe = nullptr;  // [gate word | status | queries of the batch | result slab]
-  size_t h_pipe_bytes = 0;
   void* d_q = nullptr;
   size_t d_q_bytes = 0;
   void* d_out = nullptr;
@@ -584,7 +583,7 @@ int fnv_index_free(fnv_index_t ix) {
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (ix->h_pin) (void)hipHostFree(ix->h_pin);
-  if (ix->h_pipe) (void)hipHostFree(ix->h_pipe);
+  if (ix->h_res) (void)hipHostFree(ix->h_res);
   if (ix->ev0) (void)hipEventDestroy(ix->ev0);
   if (ix->ev1) (void)hipEventDestroy(ix->ev1);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -679,12 +678,11 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   else if (n == "visited_tag_bits") ix->visited_tag_bits = value;
   else if (n == "tune_layout") ix->tune_layout = value;
   else if (n == "shadow_exact") ix->shadow_exact = value;
-  else if (n == "host_pipeline") ix->host_pipeline = value;
   else return fail(FNV_ERR_INVALID, "unknown option: " + n);
   // What fnv_tune measured (kernel variant, LDS layout) stays valid across options that change neither the launch plan
   // nor the kernel choice: Index.h::addBatchDevice flips output_node_ids around every device build, and a tune costs
   // dozens of launches.  (output_node_ids is read per launch; shadow_exact per launch; tune_layout by fnv_tune itself.)
-  const bool keeps_tuning = n == "output_node_ids" || n == "shadow_exact" || n == "tune_layout" || n == "host_pipeline";
+  const bool keeps_tuning = n == "output_node_ids" || n == "shadow_exact" || n == "tune_layout";
   if (!keeps_tuning) {
     ix->options_version++;
     ix->tuner.clear();
@@ -698,7 +696,7 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
 static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq, int K, int ef_search,
                               int num_initializations, float* d_out_dist, int32_t* d_out_labels, int32_t* d_out_count,
                               uint64_t* d_out_ndist, uint64_t* d_out_nhops, void* hip_stream, bool node_ids,
-                              int force_variant = -1, const uint32_t* gate = nullptr);
+                              int force_variant = -1);
 
 int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, int K, int ef_search,
                             int num_initializations, float* d_out_dist, int32_t* d_out_labels,
@@ -855,9 +853,8 @@ static int grow(void** buf, size_t* have, size_t need, bool zero = false) {
 static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq, int K, int ef_search,
                               int num_initializations, float* d_out_dist, int32_t* d_out_labels, int32_t* d_out_count,
                               uint64_t* d_out_ndist, uint64_t* d_out_nhops, void* hip_stream, bool node_ids,
-                              int force_variant,    // >= 0: fnv_tune's launches (an argument, not index state: a concurrent
+                              int force_variant) {  // >= 0: fnv_tune's launches (an argument, not index state: a concurrent
                                                     // caller's launch on the same handle is never forced)
-                              const uint32_t* gate) {  // non-null: queries [0, *gate) have been staged (search_host_gated)
   if (!ix) return fail(FNV_ERR_INVALID, "index is null");
   // Index.h:847-849
   if (num_initializations <= 0) return fail(FNV_ERR_INVALID, "num_initializations must be greater than 0.");
@@ -1057,7 +1054,6 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   p.status = (int32_t*)(ix->d_dispenser + 1);
   p.redo_count = ix->d_dispenser + 3;  // [3] queries searched exactly after a tie, [4..7] by reason
   p.phase_cycles = ix->d_phase;
-  p.gate = gate;
   p.tail_exact = multi_round && sorted ? (uint32_t)std::min<uint64_t>((uint64_t)tail_pct * nslots / 100, nq) : 0u;
 
   HIP_TRY(hipMemsetAsync(ix->d_dispenser, 0, 8 * sizeof(uint32_t), stream));
@@ -1159,7 +1155,19 @@ static int search_host_enqueue(fnv_index_t ix, const void* queries, uint64_t nq,
     if (!rc) rc = grow(&ix->d_out, &ix->d_out_bytes, obytes);
     if (rc) return rc;
     if (pinned && !ix->h_pin) HIP_TRY(hipHostMalloc(&ix->h_pin, 1u << 20, hipHostMallocDefault));
+    // larger batches (round 4): the queries still go in as one pageable copy, but the five result arrays come back as ONE
+    // slab into pinned memory (grown on demand, up to 256 MB of results) and are scattered by the CPU -- five pageable
+    // device-to-host copies each synchronise with the runtime's staging
+    const size_t res_need = ((obytes + 63) & ~(size_t)63) + 64;
+    if (!pinned && res_need <= (256u << 20) && res_need > ix->h_res_bytes) {
+      if (ix->h_res) HIP_TRY(hipHostFree(ix->h_res));
+      ix->h_res = nullptr;
+      ix->h_res_bytes = 0;
+      HIP_TRY(hipHostMalloc(&ix->h_res, res_need + res_need / 4, hipHostMallocDefault));
+      ix->h_res_bytes = res_need + res_need / 4;
+    }
   }
+  const bool pinned_results = !pinned && ix->h_res && ((obytes + 63) & ~(size_t)63) + 64 <= ix->h_res_bytes;
   uint8_t* o = (uint8_t*)ix->d_out;
   ix->pin = PinnedCall();
   if (pinned) {
@@ -1182,6 +1190,21 @@ static int search_host_enqueue(fnv_index_t ix, const void* queries, uint64_t nq,
     c.active = true;
     c.slab = h + ooff;
     c.status = (const int32_t*)(h + soff);
+    c.nq = nq;
+    c.K = K;
+    c.o_lab = o_lab; c.o_cnt = o_cnt; c.o_nd = o_nd; c.o_nh = o_nh;
+    c.out_dist = out_dist; c.out_labels = out_labels; c.out_count = out_count; c.out_ndist = out_ndist; c.out_nhops = out_nhops;
+    return FNV_OK;
+  }
+  if (pinned_results) {
+    uint8_t* h = (uint8_t*)ix->h_res;
+    const size_t soff2 = (obytes + 63) & ~(size_t)63;
+    HIP_TRY(hipMemcpyAsync(h, o, obytes, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipMemcpyAsync(h + soff2, ix->d_dispenser + 1, sizeof(int32_t), hipMemcpyDeviceToHost, ix->stream));
+    PinnedCall& c = ix->pin;
+    c.active = true;
+    c.slab = h;
+    c.status = (const int32_t*)(h + soff2);
     c.nq = nq;
     c.K = K;
     c.o_lab = o_lab; c.o_cnt = o_cnt; c.o_nd = o_nd; c.o_nh = o_nh;
@@ -1223,93 +1246,18 @@ static int check_search_args(fnv_index_t ix, const void* queries, uint64_t nq, i
   return FNV_OK;
 }
 
-// Large host-buffer searches (SURVEY.md 8d defines the metric on the batched call INCLUDING the H2D of the queries and
-// the D2H of the results; reference: bindings.cpp:161-228 hands host arrays in and out).  Round 3 sent the whole batch
-// through one pageable hipMemcpyAsync (which blocks its caller while the runtime stages it), one launch and five pageable
-// copies back: 0.75-0.92 of the device-resident rate.  Round 4, first attempt (measured, replaced): the batch cut into
-// chunks of 512 ... 4096 queries, each its own copy + launch + copy on alternating streams -- every chunk paid a whole
-// query latency plus its own stragglers and the launches hardly overlapped: 2.4-3.3 ms where the single launch takes
-// 1.28.  What is built instead keeps ONE launch and lets the queries arrive underneath it, with no copy at all:
-//   * the batch is staged by the CPU into PINNED host memory that the GPU reads directly (a query is read once, 512 bytes
-//     over PCIe at the start of a search that lasts hundreds of microseconds; 10 000 queries per millisecond are 5 GB/s);
-//   * the kernel is launched FIRST, with a gate (SearchParams::gate) in the same pinned buffer: its dispenser hands query i
-//     out as usual, and the wave that got it waits until the gate word says that more than i queries have been staged; the
-//     CPU stages in pieces (256, 512, 1024 ... 4096 queries) and moves the gate after each, so the first searches start
-//     tens of microseconds into the call and the rest of the staging hides under them;
-//   * results are written by the kernel straight into the pinned buffer and scattered to the caller's arrays when the
-//     stream has drained: no device-side staging of queries or results, no copy engine, three API calls per search.
-// Same bytes as the plain path ("host_pipeline" = 0): the gate only delays when a query starts.
-static int search_host_gated(fnv_index_t ix, const void* queries, uint64_t nq, int K, int ef_search, int num_initializations,
-                             float* out_dist, int32_t* out_labels, int32_t* out_count, uint64_t* out_ndist,
-                             uint64_t* out_nhops) {
-  ON_DEVICE(ix->device);
-  const size_t qrow = (size_t)ix->dim * dtype_size(ix->dtype);
-  const size_t qbytes = ((size_t)nq * qrow + 63) & ~(size_t)63;
-  // one output slab: dist | labels | count | ndist | nhops
-  const size_t o_lab = (size_t)nq * K * 4;
-  const size_t o_cnt = o_lab + (size_t)nq * K * 4;
-  const size_t o_nd = (o_cnt + (size_t)nq * 4 + 7) & ~(size_t)7;
-  const size_t o_nh = o_nd + (size_t)nq * 8;
-  const size_t obytes = (o_nh + (size_t)nq * 8 + 63) & ~(size_t)63;
-  {
-    std::lock_guard<std::mutex> lock(ix->mu);
-    const size_t need = 128 + qbytes + obytes;
-    if (need > ix->h_pipe_bytes) {
-      if (ix->h_pipe) HIP_TRY(hipHostFree(ix->h_pipe));
-      ix->h_pipe = nullptr;
-      ix->h_pipe_bytes = 0;
-      // mapped into every device's address space: the GPU reads / writes it directly
-      HIP_TRY(hipHostMalloc(&ix->h_pipe, need + need / 4, hipHostMallocPortable | hipHostMallocMapped));
-      ix->h_pipe_bytes = need + need / 4;
-    }
-  }
-  uint32_t* gate = (uint32_t*)ix->h_pipe;                 // [0] queries staged so far (own 64-byte line)
-  int32_t* hstatus = (int32_t*)((uint8_t*)ix->h_pipe + 64);
-  uint8_t* hq = (uint8_t*)ix->h_pipe + 128;
-  uint8_t* ho = hq + qbytes;
-  __atomic_store_n(gate, 0u, __ATOMIC_RELEASE);            // closed (the previous call has drained: host_mu is held)
-  int rc = search_device_impl(ix, hq, nq, K, ef_search, num_initializations, (float*)ho, (int32_t*)(ho + o_lab),
-                              (int32_t*)(ho + o_cnt), (uint64_t*)(ho + o_nd), (uint64_t*)(ho + o_nh), ix->stream,
-                              ix->output_node_ids != 0, -1, gate);
-  if (rc) return rc;  // nothing was launched
-  ix->t_enqueue_ns = now_ns();
-  HIP_TRY(hipMemcpyAsync(hstatus, ix->d_dispenser + 1, sizeof(int32_t), hipMemcpyDeviceToHost, ix->stream));
-  // the queries arrive underneath the running kernel
-  for (uint64_t done = 0, size = 256; done < nq; size = std::min<uint64_t>(size * 2, 4096)) {
-    const uint64_t n = std::min<uint64_t>(size, nq - done);
-    memcpy(hq + done * qrow, (const uint8_t*)queries + done * qrow, n * qrow);
-    done += n;
-    __atomic_store_n(gate, (uint32_t)done, __ATOMIC_RELEASE);
-  }
-  HIP_TRY(hipStreamSynchronize(ix->stream));
-  ix->t_complete_ns = now_ns();
-  memcpy(out_dist, ho, (size_t)nq * K * 4);
-  memcpy(out_labels, ho + o_lab, (size_t)nq * K * 4);
-  if (out_count) memcpy(out_count, ho + o_cnt, (size_t)nq * 4);
-  if (out_ndist) memcpy(out_ndist, ho + o_nd, (size_t)nq * 8);
-  if (out_nhops) memcpy(out_nhops, ho + o_nh, (size_t)nq * 8);
-  if (*hstatus == ST_CAND_OVERFLOW)
-    return fail(FNV_ERR_CAPACITY, "candidate heap overflowed its HBM spill area; raise the spill_entries option");
-  if (*hstatus == ST_GATE_TIMEOUT)
-    return fail(FNV_ERR_RUNTIME, "host-buffer search: the kernel gave up waiting for its queries");
-  return FNV_OK;
-}
-
+// Large host-buffer searches take the plain path above: one pageable copy in, one launch, copies out (0.80-0.93 of the
+// device-resident rate).  Round 4 tried to hide the copies inside one call, twice, and measured both slower:
+// chunks of the batch as separate copy + launch + copy pipelines on two streams (every chunk pays a whole query latency
+// and its own stragglers: 2.4-3.3 ms against 1.28 ms), and ONE launch that starts before its queries are there -- reading
+// them from pinned host memory behind a gate word, results written straight back (every touch of host memory from a
+// running wave costs microseconds: 1.7-2.6 ms).  Neither is in the tree.
 int fnv_search_batch(fnv_index_t ix, const void* queries, uint64_t nq, int K, int ef_search, int num_initializations,
                      float* out_dist, int32_t* out_labels, int32_t* out_count, uint64_t* out_ndist,
                      uint64_t* out_nhops) {
   int rc = check_search_args(ix, queries, nq, K, ef_search, num_initializations, out_dist, out_labels);
   if (rc || nq == 0) return rc;
   std::lock_guard<std::mutex> host_lock(ix->host_mu);  // concurrent callers share one staging area: serialise
-  {
-    // batches that do not fit the 1 MB pinned buffer of the small-batch path: one gated launch, queries arriving under it
-    const size_t qbytes = (size_t)nq * ix->dim * dtype_size(ix->dtype);
-    const size_t obytes = (size_t)nq * ((size_t)K * 8 + 4 + 8 + 8) + 64;
-    const bool small = ((qbytes + 63) & ~(size_t)63) + ((obytes + 63) & ~(size_t)63) + 128 <= (1u << 20);
-    if (!small && nq >= 1024 && ix->host_pipeline != 0 && !ix->entry_kernel)  // (the batched entry scan reads every query up front)
-      return search_host_gated(ix, queries, nq, K, ef_search, num_initializations, out_dist, out_labels, out_count, out_ndist,
-                               out_nhops);
-  }
   rc = search_host_enqueue(ix, queries, nq, K, ef_search, num_initializations, out_dist, out_labels, out_count,
                            out_ndist, out_nhops);
   if (rc) return rc;

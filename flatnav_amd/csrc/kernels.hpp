@@ -173,26 +173,6 @@ __device__ __forceinline__ int next_query(int lane) {
   if (lane == 0) qi = (int)atomicAdd(c->dispenser, 1u);
   qi = rfl(qi);
   if ((uint32_t)qi >= c->nq) return -1;
-  // Host-buffer searches: the kernel runs ahead of the CPU that stages its queries (search_params.h `gate`).  Wait -- one
-  // look at the pinned word every few microseconds (thousands of waves wait at the start of a launch: their looks cross
-  // PCIe), nothing else of this wave is in flight -- until the query of this work item has been staged.  A gate that does
-  // not open within ~2 s ends the launch with ST_GATE_TIMEOUT instead of hanging the device.
-  const uint32_t* gate = c->gate;
-  if (gate != nullptr) {
-    const uint32_t sb = c->shadow_base;
-    const uint32_t q = (sb != 0u && (uint32_t)qi >= sb) ? 2u * sb - 1u - (uint32_t)qi : (uint32_t)qi;  // a shadow's query
-    const unsigned long long t0 = __builtin_readcyclecounter();
-    while (true) {
-      const uint32_t staged = __hip_atomic_load(gate, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-      if ((uint32_t)rfl((int)staged) > q) break;
-      if (__builtin_readcyclecounter() - t0 > 4000000000ull) {
-        if (lane == 0) atomicMax(cold_args()->status, (int)ST_GATE_TIMEOUT);
-        return -1;
-      }
-      __builtin_amdgcn_s_sleep(127);
-      __builtin_amdgcn_s_sleep(127);
-    }
-  }
   return qi;
 }
 

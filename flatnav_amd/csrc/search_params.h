@@ -50,7 +50,7 @@ constexpr int waves_per_simd(int deflt) {
 constexpr int MB_R = 4;                   // merged-beam kernel: 64-entry chunks of the beam held in registers
 constexpr int MB_MAX_BEAM = MB_R * WAVE;  // ... = the widest beam it serves
 
-enum : int { ST_OK = 0, ST_CAND_OVERFLOW = 1, ST_GATE_TIMEOUT = 2 };
+enum : int { ST_OK = 0, ST_CAND_OVERFLOW = 1 };
 enum : uint32_t { SH_NONE = 0u, SH_ANSWERED = 1u, SH_SHADOW = 2u, SH_OWN_RERUN = 3u };  // done_flags (exact shadows, below)
 constexpr int SCAN_WAVES = 4;  // entry_scan_kernel (K0): waves per workgroup ...
 constexpr int SCAN_QPB = 32;   // ... and queries per workgroup
@@ -116,10 +116,6 @@ struct SearchParams {
   // the slots that the drain leaves idle run the exact search of the queries still under way; a tie then costs one
   // exact-search latency from the query's start, paid by a slot that had nothing else to do.  0 = off.
   uint32_t shadow_base;
-  // Gate of a host-buffer search (beam_search.hip: search_host_gated): null, or a word in pinned host memory that says how
-  // many queries of the batch the CPU has staged so far -- the kernel is launched before its queries are there (it reads
-  // them straight from the pinned buffer), and a wave that was handed query i waits until *gate > i.
-  const uint32_t* gate;
   uint32_t* done_flags;
 };
 

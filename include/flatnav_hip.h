@@ -195,11 +195,6 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *                     the same query on another slot; a query in which equal distances meet at a decision is then
  *                     answered after one exact-search latency from the start of the launch instead of a merged-beam pass
  *                     plus a re-run, the shadow of a query that needs none stops at its next hop.  0 = off.  Same bytes.
- *   "host_pipeline"   1 (default): a host-buffer batch above the 1 MB pinned staging buffer is searched by ONE launch that
- *                     starts before its queries are there: the CPU stages them piece by piece into pinned, GPU-mapped memory
- *                     that the kernel reads directly, a gate word tells the kernel how far the staging has got, results are
- *                     written straight back into the pinned buffer (fnv_search_batch); 0 = one pageable copy in, the
- *                     launch, pageable copies out (A/B measurements).  Same bytes.
  *   "tune_layout"     1 (default): fnv_tune also measures the LDS layout (see fnv_tune); 0 = kernel variants only
  *   "sorted_beam_min" smallest beam width the merged-beam kernel is used for (default 1)
  *   "sorted_cand_lds" where the exact re-run of the merged-beam kernel keeps its candidates heap: 2 (default) = in LDS

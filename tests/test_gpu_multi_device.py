@@ -141,8 +141,7 @@ def test_index_view_shares_buffers_and_overlaps_launches(oracle_mod):
 
 def test_eight_shards_of_the_bench_shape_are_all_in_flight_together(oracle_mod):
     # The 8-GPU shape of fnv_search_batch_multi on the ONE GPU of the test box (a device may be listed more than once):
-    # 80 000 host queries over eight handles = eight shards of 10 000, each driven by its own host thread (its launch starts
-    # before its queries are staged: search_host_gated).  Every shard must have been enqueued before ANY shard completed (eight devices would all be
+    # 80 000 host queries over eight handles = eight shards of 10 000, each driven by its own host thread.  Every shard must have been enqueued before ANY shard completed (eight devices would all be
     # working at once), the caller's device stays what it was, and the bytes equal one handle's answer.
     import torch
 
@@ -167,6 +166,6 @@ def test_eight_shards_of_the_bench_shape_are_all_in_flight_together(oracle_mod):
     assert np.array_equal(got[1], want[1]) and np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
     assert all(np.array_equal(got[2][k], want[2][k]) for k in ("count", "n_dist", "n_hops"))
     assert torch.cuda.current_device() == before
-    # the same 80 000 queries through ONE handle (one gated launch, 21 staging pieces)
+    # the same 80 000 queries through ONE handle
     one = src.search(Q, 10, 64, stats=True)
     assert np.array_equal(one[1], want[1]) and all(np.array_equal(one[2][k], want[2][k]) for k in ("count", "n_dist", "n_hops"))

@@ -1,8 +1,7 @@
 """Round 4 on the GPU, all through the C ABI and against the CPU oracle (bit-exact on integer-valued data):
   * rows of exactly 3 KB keep their query in registers (csrc/distance.hpp `query_in_regs`): every kernel form, every element
     type, a dimension that leaves the last chunk partly empty;
-  * large host-buffer searches are one launch that starts before its queries are staged (`search_host_gated`: queries read
-    from pinned host memory behind a gate word, results written straight back): the plain path's bytes, whatever the batch;
+  * large host-buffer batches get their results back as one pinned slab; tail shadows (variant 6) can be pinned;
   * `fnv_index_adopt`: a handle on buffers somebody else owns;
   * options that cannot change the launch plan leave fnv_tune's result alone."""
 import numpy as np
@@ -83,13 +82,11 @@ def test_three_kilobyte_rows_keep_the_query_in_registers(oracle_mod, hipmod, dt,
 
 
 @pytest.mark.parametrize("dt", ["float32", "uint8"])
-def test_gated_host_search_returns_the_plain_paths_bytes(oracle_mod, hipmod, dt):
-    # Host-buffer batches above the 1 MB pinned buffer: ONE launch that starts before its queries are staged -- the kernel
-    # reads them from pinned host memory, a gate word tells it how far the CPU has got (256, 512, 1024 ... queries at a
-    # time), results are written straight back into the pinned buffer.  Whatever the batch size (one query past a piece
-    # boundary, odd sizes), the kernel variant (tuned: an exact tail; pinned ones, tail shadows included) or the beam
-    # width, ids, distances, counts and counters are the oracle's; consecutive calls with DIFFERENT queries never see each
-    # other's data; null output arrays are left alone.
+def test_large_host_batches_come_back_through_the_pinned_result_slab(oracle_mod, hipmod, dt):
+    # Host-buffer batches above the 1 MB pinned buffer: queries in as one pageable copy, the five result arrays back as ONE
+    # slab into pinned memory, scattered by the CPU (round 4).  Whatever the batch size, kernel variant (tuned: an exact
+    # tail; pinned ones, tail shadows included) or beam width, ids, distances, counts and counters are the oracle's;
+    # consecutive calls with DIFFERENT queries never see each other's data; null output arrays are left alone.
     X, Q = ds.sift_like(20000, 24000)
     X, Q = X.astype(dt), Q.astype(dt)
     Qa, Qb = Q[:12000], Q[12000:]
@@ -103,28 +100,22 @@ def test_gated_host_search_returns_the_plain_paths_bytes(oracle_mod, hipmod, dt)
     def cut(w, n):
         return tuple(x[:n] if not isinstance(x, dict) else {k: v[:n] for k, v in x.items()} for x in w)
 
-    for nq in (12000, 3585, 3584, 2049, 7681, 1024 if dt == "uint8" else 2100):
+    for nq in (12000, 3585, 2049, 7681, 1024 if dt == "uint8" else 2100):
         _assert_exact(cut(want_a, nq), dev.search(Qa[:nq], K, ef, stats=True), "nq=%d" % nq)
         _assert_exact(cut(want_b, nq), dev.search(Qb[:nq], K, ef, stats=True), "other queries, nq=%d" % nq)
     d_only, l_only = dev.search(Qa[:5000], K, ef)  # no count / counter arrays
     assert np.array_equal(l_only, want_a[1][:5000]) and np.array_equal(d_only.view(np.uint32), want_a[0][:5000].view(np.uint32))
-    # after fnv_tune (integer-valued data: a tail variant wins)
-    dev.tune(Qa[:10000], K, ef)
+    dev.tune(Qa[:10000], K, ef)  # integer-valued data: a tail variant wins
     _assert_exact(want_a, dev.search(Qa, K, ef, stats=True), "tuned")
-    for variant in (0, 1, 3, 6):
+    for variant in (0, 1, 3, 6):  # 6: tail shadows (pinnable only)
         dev.set_option("sorted_variant", variant)
         _assert_exact(want_b, dev.search(Qb, K, ef, stats=True), "variant %d" % variant)
-        _assert_exact(want_a, dev.search(Qa, K, ef, stats=True), "variant %d" % variant)
+        assert dev.launch_info()["variant_id"] == variant
     dev.set_option("sorted_variant", -1)
-    # the plain path gives the same bytes, and so does a view of the handle
-    dev.set_option("host_pipeline", 0)
-    _assert_exact(want_b, dev.search(Qb, K, ef, stats=True), "plain path")
-    dev.set_option("host_pipeline", 1)
     view = dev.view()
     _assert_exact(want_a, view.search(Qa, K, ef, stats=True), "view")
     view.close()
-    _assert_exact(want_b, dev.search(Qb, K, ef, stats=True), "after the view")
-    # wide beams through the same path (LDS form of the merged-beam kernel, spills of the visited set), two-heap kernel
+    # wide beams (LDS form of the merged-beam kernel, spills of the visited set), then the two-heap kernel
     dev.set_option("visited_slots", 512)
     w2 = ix.search(Qa[:3000], 5, 300, stats=True, threads=8)
     _assert_exact(w2, dev.search(Qa[:3000], 5, 300, stats=True), "ef=300")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: the host-buffer entry point (fnv_search_batch: queries and results in host memory, SURVEY.md 8d's
-metric definition) against the device-pointer entry point, and its chunked pinned pipeline ("host_pipeline" = 1) against
-the single-launch path (0), alternating in one process.  Prints ms per 10 000-query call and queries/s."""
+metric definition) against the device-pointer entry point, in one process.  Prints ms per 10 000-query call and
+queries/s.  (Round 4 used it to measure two attempts at hiding the copies inside one call -- see DESIGN.md 5.)"""
 import argparse, ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -48,13 +48,8 @@ def host_calls(n):
 
 device_calls(3)
 print("%s ef=%d device-resident: %.3f ms per call (%.0f q/s)" % (args.config, args.ef, (d := device_calls(args.calls)), NQ / d * 1e3), flush=True)
-ref = None
 for rnd in range(3):
-    for mode in (0, 1):
-        dev.set_option("host_pipeline", mode)
-        host_calls(2)
-        ts, r = host_calls(args.calls)
-        if ref is None: ref = r
-        assert np.array_equal(ref[1], r[1]) and np.array_equal(ref[0], r[0])
-        print("host_pipeline=%d: median %.3f ms  min %.3f  max %.3f  -> %.0f q/s (%.2f of the device-resident rate)"
-              % (mode, np.median(ts), min(ts), max(ts), NQ / np.median(ts) * 1e3, d / np.median(ts)), flush=True)
+    host_calls(2)
+    ts, r = host_calls(args.calls)
+    print("host buffers: median %.3f ms  min %.3f  max %.3f  -> %.0f q/s (%.2f of the device-resident rate)"
+          % (np.median(ts), min(ts), max(ts), NQ / np.median(ts) * 1e3, d / np.median(ts)), flush=True)

@@ -1,111 +1,134 @@
 #!/usr/bin/env python3
-"""Condenses gpurun_out/profile_set (tools/collect_profiles.sh) into the tracked files under profiles/."""
-import csv, collections, glob, json, os, shutil, sys
+"""Condenses gpurun_out/profile_set (tools/dev/collect_profiles.sh) into the tracked files under profiles/:
+  <tag>_bench.json                         the default bench invocation's line (every configuration)
+  <tag>_kernel_trace_timed_regions.csv     per configuration: the timed region's search launches from rocprofv3's kernel trace
+  <tag>_rocprofv3_kernel_stats_<cfg>.csv   rocprofv3 --stats of the same command (all launches of the process)
+  <tag>_pmc_hbm_traffic.json               per configuration: FETCH_SIZE / WRITE_SIZE per launch, corrected as the guide prescribes
+  <tag>_sq_counters.json                   instruction mix / wait counters, float32 headline and uint8 index"""
+import collections, csv, glob, json, os, shutil, sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 O = os.path.join(ROOT, "gpurun_out", "profile_set")
 P = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
+CONFIGS = ["c2", "c2-uint8", "c4", "c3-lowrank", "c3", "c5", "c5-lowrank"]
 
 
 def find(d, suffix):
     hits = glob.glob(os.path.join(O, d, "**", "*" + suffix), recursive=True)
-    if not hits:
-        raise SystemExit("no %s under %s" % (suffix, d))
-    return hits[0]
+    return hits[0] if hits else None
 
 
 bench = json.load(open(os.path.join(O, "bench.json")))
 shutil.copy(os.path.join(O, "bench.json"), os.path.join(P, "%s_bench.json" % tag))
-shutil.copy(os.path.join(O, "bench_uint8.json"), os.path.join(P, "%s_bench_uint8.json" % tag))
-shutil.copy(find("trace", "kernel_stats.csv"), os.path.join(P, "%s_rocprofv3_kernel_stats.csv" % tag))
-shutil.copy(find("trace_uint8", "kernel_stats.csv"), os.path.join(P, "%s_rocprofv3_kernel_stats_uint8.csv" % tag))
 
 
-def bench_launches(d, out_name, steps=20):
-    """The timed region's launches from the kernel trace: the last `steps` full-size (4096-slot) search launches.  The
-    raw --stats table also averages the index construction's and the ef sweep's launches of the same kernels."""
-    rows = [r for r in csv.DictReader(open(find(d, "kernel_trace.csv"))) if "beam_search" in r["Kernel_Name"]]
-    full = [r for r in rows if int(r["Grid_Size_X"]) == max(int(x["Grid_Size_X"]) for x in rows)]
-    last = sorted(full, key=lambda r: int(r["Start_Timestamp"]))[-steps:]
-    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last]
-    names = collections.Counter(r["Kernel_Name"] for r in last)
-    with open(os.path.join(P, out_name), "w") as f:
-        f.write("# the last %d full-grid search launches of the profiled bench command (= its timed region), from rocprofv3's kernel trace\n" % steps)
-        f.write("Kernel_Name,Calls,AverageNs,MinNs,MaxNs,Grid_Size,Workgroup_Size,LDS_Block_Size,VGPR_Count,SGPR_Count,Scratch_Size\n")
-        for name, calls in names.items():
-            sel = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last if r["Kernel_Name"] == name]
-            r0 = next(r for r in last if r["Kernel_Name"] == name)
-            f.write('"%s",%d,%.1f,%d,%d,%s,%s,%s,%s,%s,%s\n' % (name, calls, sum(sel) / len(sel), min(sel), max(sel), r0["Grid_Size_X"],
-                    r0["Workgroup_Size_X"], r0.get("LDS_Block_Size", ""), r0.get("VGPR_Count", ""), r0.get("SGPR_Count", ""), r0.get("Scratch_Size", "")))
-    return sum(dur) / len(dur) / 1e6
+def entry(c):
+    return bench if c == "c2" else bench.get(c)
+
+
+def timed_launches(c, steps):
+    """The timed region of the profiled command = its last `steps` full-grid search launches (tuning, warm-up, the
+    byte-count launches after the timed region and the recall checks launch the same kernels: bench.py's order is
+    tune, warm-up, TIMED, counters, recall -- so the timed ones are found by position from the end)."""
+    f = find("trace_" + c, "kernel_trace.csv")
+    if not f:
+        return None
+    rows = [r for r in csv.DictReader(open(f)) if "beam_search" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    big = max(int(r["Grid_Size_X"]) for r in rows)
+    full = [r for r in rows if int(r["Grid_Size_X"]) == big]
+    j = json.load(open(os.path.join(O, "trace_%s.json" % c)))
+    after, steps = j["roofline"]["trace_position"]["after"], j["roofline"]["trace_position"]["timed"]  # counted by bench.py itself
+    sel = full[-(after + steps):-after]
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in sel]
+    r0 = sel[0]
+    return {"config": c, "kernel": r0["Kernel_Name"], "calls": len(sel), "avg_ns": sum(dur) / len(dur), "min_ns": min(dur), "max_ns": max(dur),
+            "grid": r0["Grid_Size_X"], "workgroup": r0["Workgroup_Size_X"], "lds": r0.get("LDS_Block_Size", ""), "vgpr": r0.get("VGPR_Count", ""),
+            "sgpr": r0.get("SGPR_Count", ""), "scratch": r0.get("Scratch_Size", ""),
+            "bench_events_avg_ms": j["roofline"]["avg_kernel_ms"], "algorithmic_bytes_per_launch": j["roofline"]["algorithmic_bytes_per_launch"],
+            "ef": j["config"]["ef_search"]}
 
 
 def counters(d, steps=3):
-    """Per-launch averages over the profiled command's timed region: its last `steps` full-grid search launches (the
-    index construction and the ef sweep launch search kernels too -- other instantiations, or the same one earlier)."""
-    rows = [r for r in csv.DictReader(open(find(d, "counter_collection.csv"))) if "beam_search" in r["Kernel_Name"]]
-    ids = sorted({int(r["Dispatch_Id"]) for r in rows})[-steps:]  # the timed steps are the command's last launches
+    f = find(d, "counter_collection.csv")
+    if not f:
+        return None, None
+    after = None
+    try:
+        pos = json.load(open(os.path.join(O, d + ".json")))["roofline"]["trace_position"]
+        after, steps = pos["after"], pos["timed"]
+    except (OSError, KeyError, ValueError):
+        pass
+    rows = [r for r in csv.DictReader(open(f)) if "beam_search" in r["Kernel_Name"]]
+    big = max(int(r["Grid_Size"]) for r in rows)
+    rows = [r for r in rows if int(r["Grid_Size"]) == big]
+    ids = sorted({int(r["Dispatch_Id"]) for r in rows})
+    if after is None:  # (a pass whose bench line was not kept: same command as the FETCH pass of the same configuration)
+        pos = json.load(open(os.path.join(O, "fetch_" + d.split("_", 1)[1] + ".json")))["roofline"]["trace_position"]
+        after, steps = pos["after"], pos["timed"]
+    ids = ids[-(after + steps):-after]
     rows = [r for r in rows if int(r["Dispatch_Id"]) in ids]
-    kernel = rows[-1]["Kernel_Name"]
-    assert all(r["Kernel_Name"] == kernel for r in rows), "timed region mixes kernels"
     acc = collections.defaultdict(list)
     for r in rows:
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     first = rows[0]
-    meta = {k: first[k] for k in ("Grid_Size", "Workgroup_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Kernel_Name")}
+    meta = {k: first[k] for k in ("Grid_Size", "Workgroup_Size", "Scratch_Size", "VGPR_Count", "SGPR_Count", "Kernel_Name") if k in first}
     return {k: sum(v) / len(v) for k, v in acc.items()}, meta
 
 
-avg_ms = bench_launches("trace", "%s_rocprofv3_bench_launches.csv" % tag)
-avg_ms_u8 = bench_launches("trace_uint8", "%s_rocprofv3_bench_launches_uint8.csv" % tag)
-print("timed-region launches under rocprofv3: float32 %.4f ms, uint8 %.4f ms (bench.py's own events: %.4f ms)" %
-      (avg_ms, avg_ms_u8, bench["roofline"]["avg_kernel_ms"]))
-traffic, sq = [], {}
-for dt in ("float32", "uint8"):
-    f, meta = counters("fetch_" + dt)
-    w, _ = counters("write_" + dt)
-    F, W = f["FETCH_SIZE"], w["WRITE_SIZE"]
-    traffic.append({
-        "config": "c2", "dtype": dt, "n": 1000000, "nq": 10000, "ef": bench["config"]["ef_search"], "kernel": meta,
-        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --no-cpu-baseline "
-                   "--no-secondary --sustain-seconds 0 --ef %d --dtype %s --steps 3 --warmup 5" % (bench["config"]["ef_search"], dt),
-        "FETCH_SIZE_KB_per_launch": F, "WRITE_SIZE_KB_per_launch": W,
-        "correction": "MI355X_MICROARCH.md HBM section: hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024; on gfx950 FETCH_SIZE tallies each "
-                      "128-B request of a 16 B/lane coalesced read as 64 B -> read side doubled",
-        "hbm_bytes_per_launch_uncorrected": (F + W) * 1024, "hbm_bytes_per_launch_corrected": (2 * F + W) * 1024,
-    })
-    c, m = counters("sq_" + dt)
-    sq[dt] = {"kernel": m, "per_launch": c}
-for efw in (110, 200, 400):  # 100-d rows (config c4): 400-byte rows at a 512-byte stride since round 3
-    try:
-        wb = json.load(open(os.path.join(O, "bench_c4_ef%d.json" % efw)))
-        f, meta = counters("fetch_c4_ef%d" % efw)
-        w, _ = counters("write_c4_ef%d" % efw)
+trace_rows, traffic, sq = [], [], {}
+for c in CONFIGS:
+    e = entry(c)
+    if e is None:
+        continue
+    steps = 6 if c.startswith(("c3", "c5")) else 20
+    t = timed_launches(c, steps)
+    if t:
+        trace_rows.append(t)
+        st = find("trace_" + c, "kernel_stats.csv")
+        if st:
+            shutil.copy(st, os.path.join(P, "%s_rocprofv3_kernel_stats_%s.csv" % (tag, c)))
+    f, meta = counters("fetch_" + c)
+    w, _ = counters("write_" + c)
+    if f and w:
         F, W = f["FETCH_SIZE"], w["WRITE_SIZE"]
-        r = wb["roofline"]
+        fj = json.load(open(os.path.join(O, "fetch_%s.json" % c)))
+        r = fj["roofline"]
         corrected = (2 * F + W) * 1024
-        traffic.append({"config": "c4", "dtype": "float32", "n": 1183514, "nq": 10000, "ef": efw, "kernel": meta,
-                        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --config c4 --no-cpu-baseline "
-                                   "--no-secondary --sustain-seconds 0 --ef %d --steps 3 --warmup 3" % efw,
-                        "FETCH_SIZE_KB_per_launch": F, "WRITE_SIZE_KB_per_launch": W,
-                        "hbm_bytes_per_launch_uncorrected": (F + W) * 1024, "hbm_bytes_per_launch_corrected": corrected,
-                        "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
-                        "line_bytes_per_launch": r["line_bytes_per_launch"],
-                        "traffic_over_algorithmic": corrected / r["algorithmic_bytes_per_launch"],
-                        "traffic_over_line_bytes": corrected / r["line_bytes_per_launch"],
-                        "row_bytes": r["row_bytes"], "row_stride_bytes": r["row_stride_bytes"],
-                        "note": "100-d float32 rows: 400 bytes of data in a 512-byte (four-line) stride; the write side is the visited "
-                                "set's per-slot HBM bitmap (ids beyond the LDS table: read-modify-write of one line each)"})
-    except (OSError, KeyError, SystemExit) as e:
-        print("no c4 pass at ef=%d:" % efw, e)
-json.dump([t for t in traffic if t["dtype"] == "float32"] + [t for t in traffic if t["dtype"] != "float32"],
-          open(os.path.join(P, "%s_pmc_hbm_traffic.json" % tag), "w"), indent=1)
-json.dump({"ef": bench["config"]["ef_search"], "counters": sq}, open(os.path.join(P, "%s_sq_counters.json" % tag), "w"), indent=1)
-print(json.dumps({"value": bench["value"], "ef": bench["config"]["ef_search"], "recall": bench["config"]["recall_at_10"],
-                  "frac": bench["roofline"]["frac"], "avg_kernel_ms": bench["roofline"]["avg_kernel_ms"],
-                  "cpu": bench["cpu_baseline"]["value"], "launch": bench["config"]["launch"]}))
-print(open(os.path.join(P, "%s_rocprofv3_kernel_stats.csv" % tag)).read()[:600])
+        traffic.append({
+            "config": c.replace("-uint8", ""), "dtype": "uint8" if c.endswith("uint8") else "float32",
+            "n": int(fj["config"]["index_bytes_in_hbm"] // (r["row_stride_bytes"] + 132)), "nq": 10000, "ef": fj["config"]["ef_search"], "kernel": meta,
+            "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --config %s --ef %d "
+                       "--no-cpu-baseline --no-secondary --sustain-seconds 0 --warmup 3 --steps 3" % (c, fj["config"]["ef_search"]),
+            "FETCH_SIZE_KB_per_launch": F, "WRITE_SIZE_KB_per_launch": W,
+            "correction": "MI355X_MICROARCH.md HBM section: hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024; on gfx950 FETCH_SIZE tallies each "
+                          "128-B request of a 16 B/lane coalesced read as 64 B -> read side doubled",
+            "hbm_bytes_per_launch_uncorrected": (F + W) * 1024, "hbm_bytes_per_launch_corrected": corrected,
+            "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "line_bytes_per_launch": r["line_bytes_per_launch"],
+            "traffic_over_algorithmic": corrected / r["algorithmic_bytes_per_launch"],
+            "traffic_over_line_bytes": corrected / r["line_bytes_per_launch"],
+            "kernel_ms_under_pmc": r["avg_kernel_ms"]})
+    s, m = counters("sq_" + c)
+    if s:
+        sq[c] = {"kernel": m, "per_launch": s}
+with open(os.path.join(P, "%s_kernel_trace_timed_regions.csv" % tag), "w") as fo:
+    fo.write("# per configuration: the timed region's search launches of `rocprofv3 --kernel-trace --stats -- python3 bench.py --config <c> --ef <ef> "
+             "--no-cpu-baseline --no-secondary --sustain-seconds 0 --warmup 3 --steps <calls>` (positions from the end of the process's full-grid launches)\n")
+    cols = ["config", "ef", "kernel", "calls", "avg_ns", "min_ns", "max_ns", "grid", "workgroup", "lds", "vgpr", "sgpr", "scratch", "bench_events_avg_ms",
+            "algorithmic_bytes_per_launch"]
+    fo.write(",".join(cols) + ",achieved_GBps,frac_of_8TBps\n")
+    for t in trace_rows:
+        gbps = t["algorithmic_bytes_per_launch"] / t["avg_ns"]
+        fo.write(",".join('"%s"' % t[k] if k == "kernel" else str(t[k]) for k in cols) + ",%.1f,%.4f\n" % (gbps, gbps / 8000.0))
+json.dump(traffic, open(os.path.join(P, "%s_pmc_hbm_traffic.json" % tag), "w"), indent=1)
+json.dump(sq, open(os.path.join(P, "%s_sq_counters.json" % tag), "w"), indent=1)
+for t in trace_rows:
+    e = entry(t["config"])
+    print("%-11s ef=%-4d trace %.4f ms  bench-under-trace %.4f ms  default-run %.4f ms  frac(trace) %.3f  frac(default run) %.3f  scratch %s vgpr %s" % (
+        t["config"], t["ef"], t["avg_ns"] / 1e6, t["bench_events_avg_ms"], e["roofline"]["avg_kernel_ms"],
+        t["algorithmic_bytes_per_launch"] / t["avg_ns"] / 8000.0, e["roofline"]["frac"], t["scratch"], t["vgpr"]))
 for t in traffic:
-    print(t["dtype"], "traffic GB", t["hbm_bytes_per_launch_corrected"] / 1e9, t["kernel"]["Kernel_Name"][:60])
-for dt, v in sq.items():
-    print(dt, {k: round(x / 1e6, 1) for k, x in v["per_launch"].items()})
+    print("%-11s %-7s ef=%-4d traffic %.2f GB = %.3f x algorithmic (%.3f x line bytes)  write %.2f GB" % (
+        t["config"], t["dtype"], t["ef"], t["hbm_bytes_per_launch_corrected"] / 1e9, t["traffic_over_algorithmic"], t["traffic_over_line_bytes"],
+        t["WRITE_SIZE_KB_per_launch"] * 1024 / 1e9))
