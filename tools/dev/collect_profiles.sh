@@ -11,6 +11,11 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/profile_set
 mkdir -p $O
 CONFIGS=${@:-c2 c2-uint8 c4 c3-lowrank c3 c5 c5-lowrank}
+# (a GPU box starts without gpurun_out/: later calls for a subset of the configurations take the efs from the bench line
+#  that an earlier call left -- copied to profiles/<tag>_bench.json, which travels with the repo)
+if [ ! -s $O/bench.json ] && [ -s $R/profiles/${PROFILE_TAG:-r4}_bench.json ] && [ -n "${PROFILE_REUSE_BENCH:-}" ]; then
+  cp $R/profiles/${PROFILE_TAG:-r4}_bench.json $O/bench.json
+fi
 if [ ! -s $O/bench.json ]; then
   python $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.log
 fi
@@ -30,5 +35,16 @@ print(e['config']['ef_search'])")
   case $C in c2|c2-uint8)
     rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/sq_$C -o bench -- python3 $R/bench.py $ARGS --steps 3 > $O/sq_$C.json 2> /dev/null;;
   esac
+  # gpurun brings back 64 MB and the raw rocprofv3 output of a 50M-node build is hundreds: keep the search kernels' rows of
+  # the traces / counter files and the --stats table, drop the rest; summarise here as well (summary/<config>.json)
+  for D in $O/trace_$C $O/fetch_$C $O/write_$C $O/sq_$C; do
+    [ -d $D ] || continue
+    find $D -type f \( -name '*kernel_trace.csv' -o -name '*counter_collection.csv' \) | while read F; do
+      { head -1 "$F"; grep beam_search "$F"; } > "$F.small" && mv "$F.small" "$F"
+    done
+    find $D -type f ! -name '*kernel_trace.csv' ! -name '*counter_collection.csv' ! -name '*kernel_stats.csv' -delete
+  done
+  python3 $R/tools/dev/summarise_profiles.py --one $C >> $O/summary.log 2>&1
+  tail -2 $O/summary.log
 done
-ls $O | head -60
+du -sh $O; ls $O $O/summary | head -60

@@ -20,7 +20,8 @@ def find(d, suffix):
 
 
 bench = json.load(open(os.path.join(O, "bench.json")))
-shutil.copy(os.path.join(O, "bench.json"), os.path.join(P, "%s_bench.json" % tag))
+if not (len(sys.argv) > 2 and sys.argv[1] == "--one"):
+    shutil.copy(os.path.join(O, "bench.json"), os.path.join(P, "%s_bench.json" % tag))
 
 
 def entry(c):
@@ -36,9 +37,11 @@ def timed_launches(c, steps):
         return None
     rows = [r for r in csv.DictReader(open(f)) if "beam_search" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    big = max(int(r["Grid_Size_X"]) for r in rows)
-    full = [r for r in rows if int(r["Grid_Size_X"]) == big]
     j = json.load(open(os.path.join(O, "trace_%s.json" % c)))
+    # the launches of the timed region and everything bench.py launched after it have the geometry the line reports (the
+    # device builder's and fnv_tune's other variants launch other grids); rocprofv3 counts work-items
+    blocks = j["config"]["launch"]["grid_blocks"]
+    full = [r for r in rows if int(r["Grid_Size_X"]) in (blocks, blocks * 64)]
     after, steps = j["roofline"]["trace_position"]["after"], j["roofline"]["trace_position"]["timed"]  # counted by bench.py itself
     sel = full[-(after + steps):-after]
     dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in sel]
@@ -61,8 +64,11 @@ def counters(d, steps=3):
     except (OSError, KeyError, ValueError):
         pass
     rows = [r for r in csv.DictReader(open(f)) if "beam_search" in r["Kernel_Name"]]
-    big = max(int(r["Grid_Size"]) for r in rows)
-    rows = [r for r in rows if int(r["Grid_Size"]) == big]
+    jd = os.path.join(O, d + ".json")
+    if not os.path.exists(jd):
+        jd = os.path.join(O, "fetch_" + d.split("_", 1)[1] + ".json")
+    blocks = json.load(open(jd))["config"]["launch"]["grid_blocks"]
+    rows = [r for r in rows if int(r["Grid_Size"]) in (blocks, blocks * 64)]
     ids = sorted({int(r["Dispatch_Id"]) for r in rows})
     if after is None:  # (a pass whose bench line was not kept: same command as the FETCH pass of the same configuration)
         pos = json.load(open(os.path.join(O, "fetch_" + d.split("_", 1)[1] + ".json")))["roofline"]["trace_position"]
@@ -77,7 +83,28 @@ def counters(d, steps=3):
     return {k: sum(v) / len(v) for k, v in acc.items()}, meta
 
 
-trace_rows, traffic, sq = [], [], {}
+ONE = None
+if len(sys.argv) > 2 and sys.argv[1] == "--one":
+    ONE, tag = sys.argv[2], "r4"
+    CONFIGS = [ONE]
+SUM = os.path.join(O, "summary")
+os.makedirs(SUM, exist_ok=True)
+if ONE is None and not any(find("trace_" + c, "kernel_trace.csv") for c in CONFIGS):
+    # the raw rocprofv3 output was summarised on the GPU box, configuration by configuration (it is too big to come back)
+    trace_rows, traffic, sq = [], [], {}
+    for c in CONFIGS:
+        f = os.path.join(SUM, c + ".json")
+        if os.path.exists(f):
+            part = json.load(open(f))
+            trace_rows += part["trace"]
+            traffic += part["traffic"]
+            sq.update(part["sq"])
+        st = os.path.join(SUM, "kernel_stats_%s.csv" % c)
+        if os.path.exists(st):
+            shutil.copy(st, os.path.join(P, "%s_rocprofv3_kernel_stats_%s.csv" % (tag, c)))
+    CONFIGS = []
+else:
+    trace_rows, traffic, sq = [], [], {}
 for c in CONFIGS:
     e = entry(c)
     if e is None:
@@ -88,7 +115,7 @@ for c in CONFIGS:
         trace_rows.append(t)
         st = find("trace_" + c, "kernel_stats.csv")
         if st:
-            shutil.copy(st, os.path.join(P, "%s_rocprofv3_kernel_stats_%s.csv" % (tag, c)))
+            shutil.copy(st, os.path.join(SUM if ONE else P, ("kernel_stats_%s.csv" % c) if ONE else "%s_rocprofv3_kernel_stats_%s.csv" % (tag, c)))
     f, meta = counters("fetch_" + c)
     w, _ = counters("write_" + c)
     if f and w:
@@ -112,6 +139,10 @@ for c in CONFIGS:
     s, m = counters("sq_" + c)
     if s:
         sq[c] = {"kernel": m, "per_launch": s}
+if ONE:
+    json.dump({"trace": trace_rows, "traffic": traffic, "sq": sq}, open(os.path.join(SUM, ONE + ".json"), "w"), indent=1)
+    print("summarised", ONE, [round(t["avg_ns"] / 1e6, 4) for t in trace_rows], [round(t["traffic_over_algorithmic"], 3) for t in traffic])
+    sys.exit(0)
 with open(os.path.join(P, "%s_kernel_trace_timed_regions.csv" % tag), "w") as fo:
     fo.write("# per configuration: the timed region's search launches of `rocprofv3 --kernel-trace --stats -- python3 bench.py --config <c> --ef <ef> "
              "--no-cpu-baseline --no-secondary --sustain-seconds 0 --warmup 3 --steps <calls>` (positions from the end of the process's full-grid launches)\n")
