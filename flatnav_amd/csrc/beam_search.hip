@@ -412,7 +412,7 @@ int write_nodes_impl(fnv_index_s* ix, uint64_t first_node, uint64_t count_nodes,
 extern "C" {
 
 const char* fnv_last_error(void) { return g_err.c_str(); }
-const char* fnv_version(void) { return "flatnav_hip gfx950 r3"; }
+const char* fnv_version(void) { return "flatnav_hip gfx950 r4"; }
 
 int fnv_device_count(int* count) {
   if (!count) return fail(FNV_ERR_INVALID, "count is null");

@@ -216,7 +216,10 @@ int fnv_set_option(fnv_index_t index, const char* name, int64_t value);
  * out_dist/out_labels: [nq][K].  Rows with fewer than K reachable results are padded with
  * (+inf, -1) and reported through out_count[q] (nullable) -- the reference's binding raises
  * RuntimeError in that case (bindings.cpp:184-189); the host wrapper does the same.
- * out_ndist / out_nhops (nullable): per-query neighbour distance evaluations and expanded hops. */
+ * out_ndist / out_nhops (nullable): per-query neighbour distance evaluations and expanded hops.
+ * Copies: batches up to ~1 MB of queries + results go through one pinned staging buffer (one copy in, one out);
+ * larger ones take one pageable copy in and ONE copy of the whole result slab out into pinned memory (round 4),
+ * scattered to the five arrays by the CPU: 0.84-0.99 of the device-resident rate (PCIe-inclusive). */
 int fnv_search_batch(fnv_index_t index, const void* queries, uint64_t nq, int K, int ef_search,
                      int num_initializations, float* out_dist, int32_t* out_labels, int32_t* out_count,
                      uint64_t* out_ndist, uint64_t* out_nhops);
