@@ -265,7 +265,18 @@ def main() -> None:
         sub.steps, sub.warmup = max(3, min(args.steps, 10)), max(1, min(args.warmup, 3))
         sub.sustain_seconds = 0.0
         t0 = time.time()
-        entry = run_config(ctx, sub, name, main_line=False)
+        try:
+            entry = run_config(ctx, sub, name, main_line=False)
+        except Exception as exc:  # a further configuration must never take the contract line down with it
+            if world > 1:
+                raise  # (the other ranks are inside collectives: there is no recovering)
+            import traceback
+
+            traceback.print_exc()
+            out[name] = {"skipped": "failed: %s: %s" % (type(exc).__name__, str(exc)[:300])}
+            out["secondary"].append({"config": name, "skipped": True, "error": type(exc).__name__})
+            torch.cuda.empty_cache()
+            continue
         if rank == 0:
             entry["wall_seconds"] = round(time.time() - t0, 1)
             out[name] = entry

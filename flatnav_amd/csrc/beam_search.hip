@@ -224,7 +224,7 @@ constexpr int kVariantTailShadows = 6;
 static const int kTailPct[kNumVariants] = {0, 0, 50, 75, 100, 25, 0};
 static inline bool variant_allowed(int v, bool multi_round, bool try_tail, bool shadows_on, bool pinned_only = false) {
   if (v < 2) return true;
-  // (tail shadows: measured in round 4 -- within 1 % of the merged-beam kernel alone on every configuration, never the best:
+  // (tail shadows: measured in round 4 -- 0.5-3 % better than the merged-beam kernel alone, behind the best exact tail on every configuration:
   //  a shadow can only start when a slot falls idle, which is too late for the ties that end a launch -- so the variant can
   //  be pinned for A/B runs but is not part of the adaptive choice)
   if (v == kVariantTailShadows) return shadows_on && pinned_only;
