@@ -571,7 +571,27 @@ def run_config(ctx, args, config, main_line):
         for i in range(4):
             dev.search(Q_rank[(i + 1) % nb], K, EF)
         host_qps = 4 * NQ / (time.perf_counter() - t0)
-        log("[rank 0] host-buffer (PCIe-inclusive) path: %.0f queries/s" % host_qps)
+        # ... and with TWO caller threads on the one handle (the second caller runs on the handle's second lane: its copies
+        # and its launch overlap the first caller's -- the reference's search is callable from several threads at once)
+        import threading
+
+        def caller(first):
+            for i in range(first, first + 6, 2):
+                dev.search(Q_rank[i % nb], K, EF)
+        caller(0)  # (first contention creates the second lane: outside the timed region)
+        th = [threading.Thread(target=caller, args=(f,)) for f in (0, 1)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=caller, args=(f,)) for f in (0, 1)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        host2_qps = 6 * NQ / (time.perf_counter() - t0)
+        log("[rank 0] host-buffer (PCIe-inclusive) path: %.0f queries/s; two caller threads: %.0f queries/s" % (host_qps, host2_qps))
     # ---- two batches in flight (rank-local, informational): a second handle on the same HBM buffers (fnv_index_view),
     #      a second stream, launches alternate -- the drain of one launch (its last, slowest queries at falling
     #      occupancy) overlaps the start of the next.  This is the rate a server that always has the next batch ready
@@ -671,6 +691,7 @@ def run_config(ctx, args, config, main_line):
                                  % (tuned.get(EF, 0.0), main_m["explored"]),
                 "queries_replayed_by_exact_kernel": replay["total"],
                 "host_buffer_qps_pcie_inclusive": round(host_qps),
+                "host_buffer_qps_two_caller_threads": round(host2_qps),
                 "index_bytes_in_hbm": index_bytes,
                 "index_fraction_in_infinity_cache": round(min(1.0, INFINITY_CACHE_BYTES / index_bytes), 3),
                 "measured_in_this_run": "value, ms_per_step, recall, roofline.achieved/avg_kernel_ms, gather ceiling, "

@@ -302,6 +302,15 @@ struct fnv_index_s : IndexOptions {
   uint64_t geom[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::mutex mu;       // launch configuration + workspace growth
   std::mutex host_mu;  // the host-buffer entry point owns d_q / d_out / stream for the whole call
+  // Round 4: a SECOND LANE for concurrent host-buffer callers.  Two threads calling fnv_search_batch on one handle used to
+  // take turns; now the second caller runs on a hidden view of the handle (own stream, workspace and staging, the same HBM
+  // buffers), so its copies and its launch overlap the first caller's -- the reference's search is callable from several
+  // threads at once (bindings.cpp:198-211 runs it under executeInParallel), and two launches in flight are what hides a
+  // launch's ramp and drain.  Created on first contention; freed with the handle.
+  fnv_index_s* lane2 = nullptr;
+  std::mutex lane_mu;            // creation of lane2
+  uint64_t tune_epoch = 0;       // bumped whenever tuner / layouts change: lane2 copies them when its own epoch lags
+  uint64_t lane_epoch = ~0ull, lane_options = ~0ull;  // (on lane2: what it last copied from its owner)
 };
 
 namespace {
@@ -573,6 +582,11 @@ int fnv_index_info(fnv_index_t ix, uint64_t info[8]) {
 
 int fnv_index_free(fnv_index_t ix) {
   if (!ix) return FNV_OK;
+  if (ix->lane2) {  // the hidden second lane goes first (it counts as a view of this handle)
+    fnv_index_s* l2 = ix->lane2;
+    ix->lane2 = nullptr;
+    (void)fnv_index_free(l2);
+  }
   if (ix->n_views.load() > 0)
     return fail(FNV_ERR_INVALID, "fnv_index_free: the index still has live views (fnv_index_view) on its buffers; free them first");
   DeviceScope scope(ix->device);
@@ -689,6 +703,7 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
     ix->layouts.clear();
     ix->sample_kernel = -1;
   }
+  ix->tune_epoch++;  // (the second lane of the host entry point re-copies options and measurements)
   return FNV_OK;
 }
 
@@ -1246,6 +1261,31 @@ static int check_search_args(fnv_index_t ix, const void* queries, uint64_t nq, i
   return FNV_OK;
 }
 
+// The hidden second lane of a handle (fnv_index_s::lane2): created on first contention.
+static fnv_index_s* second_lane(fnv_index_t ix) {
+  std::lock_guard<std::mutex> lock(ix->lane_mu);
+  if (!ix->lane2) {
+    fnv_index_t v = nullptr;
+    if (fnv_index_view(ix, &v) != FNV_OK) return nullptr;
+    ix->lane2 = v;
+  }
+  return ix->lane2;
+}
+// The lane answers exactly like its owner: same options, same measured layouts and kernel choice (copied when they changed).
+static void sync_lane(fnv_index_t ix, fnv_index_s* lane) {
+  std::lock_guard<std::mutex> l1(ix->mu);
+  std::lock_guard<std::mutex> l2(lane->mu);
+  if (lane->lane_epoch == ix->tune_epoch && lane->lane_options == ix->options_version) return;
+  static_cast<IndexOptions&>(*lane) = static_cast<const IndexOptions&>(*ix);
+  lane->layouts = ix->layouts;
+  lane->tuner = ix->tuner;
+  lane->sample_kernel = -1;
+  lane->options_version++;
+  lane->plan.valid = false;
+  lane->lane_epoch = ix->tune_epoch;
+  lane->lane_options = ix->options_version;
+}
+
 // Large host-buffer searches take the plain path above: one pageable copy in, one launch, copies out (0.80-0.93 of the
 // device-resident rate).  Round 4 tried to hide the copies inside one call, twice, and measured both slower:
 // chunks of the batch as separate copy + launch + copy pipelines on two streams (every chunk pays a whole query latency
@@ -1257,11 +1297,30 @@ int fnv_search_batch(fnv_index_t ix, const void* queries, uint64_t nq, int K, in
                      uint64_t* out_nhops) {
   int rc = check_search_args(ix, queries, nq, K, ef_search, num_initializations, out_dist, out_labels);
   if (rc || nq == 0) return rc;
-  std::lock_guard<std::mutex> host_lock(ix->host_mu);  // concurrent callers share one staging area: serialise
-  rc = search_host_enqueue(ix, queries, nq, K, ef_search, num_initializations, out_dist, out_labels, out_count,
+  // one caller at a time per lane (a lane's staging areas, stream and workspace are its caller's for the whole call); a
+  // caller that finds the handle busy takes the second lane, a third one waits for the first
+  fnv_index_s* lane = ix;
+  std::unique_lock<std::mutex> host_lock(ix->host_mu, std::try_to_lock);
+  if (!host_lock.owns_lock() && !ix->parent) {
+    if (fnv_index_s* l2 = second_lane(ix)) {
+      std::unique_lock<std::mutex> lock2(l2->host_mu, std::try_to_lock);
+      if (lock2.owns_lock()) {
+        lane = l2;
+        host_lock = std::move(lock2);
+      }
+    }
+  }
+  if (!host_lock.owns_lock()) host_lock = std::unique_lock<std::mutex>(ix->host_mu);
+  if (lane != ix) sync_lane(ix, lane);
+  rc = search_host_enqueue(lane, queries, nq, K, ef_search, num_initializations, out_dist, out_labels, out_count,
                            out_ndist, out_nhops);
   if (rc) return rc;
-  return search_host_finish(ix);
+  rc = search_host_finish(lane);
+  if (lane != ix) {  // what fnv_last_launch_info reports for the handle: the most recent call, whichever lane served it
+    ix->t_enqueue_ns = lane->t_enqueue_ns;
+    ix->t_complete_ns = lane->t_complete_ns;
+  }
+  return rc;
 }
 
 // ---- several GPUs behind one call -----------------------------------------------------------------
@@ -1412,6 +1471,11 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
   if (K <= 0 || ef_search <= 0) return fail(FNV_ERR_INVALID, "K and ef_search must be positive");
   if (!queries || nq == 0) return fail(FNV_ERR_INVALID, "fnv_tune needs a batch of queries");
   std::lock_guard<std::mutex> host_lock(ix->host_mu);
+  std::unique_lock<std::mutex> lane2_lock;  // (no host-buffer search on the second lane meanwhile either)
+  {
+    std::lock_guard<std::mutex> lm(ix->lane_mu);
+    if (ix->lane2) lane2_lock = std::unique_lock<std::mutex>(ix->lane2->host_mu);
+  }
   ON_DEVICE(ix->device);
   const size_t qbytes = (size_t)nq * ix->dim * dtype_size(ix->dtype);
   const size_t o_lab = (size_t)nq * K * 4, obytes = 2 * o_lab;
@@ -1579,6 +1643,7 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
     std::lock_guard<std::mutex> lock(ix->mu);
     ix->tuner[2 * B + (multi_round ? 1 : 0)] = t;
     ix->sample_kernel = -1;
+    ix->tune_epoch++;
   }
   int32_t st = 0;
   HIP_TRY(hipMemcpy(&st, ix->d_dispenser + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1644,6 +1709,11 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
   if (evals_out) *evals_out = 0;
   if (count == 0) return FNV_OK;
   std::lock_guard<std::mutex> host_lock(ix->host_mu);
+  std::unique_lock<std::mutex> lane2_lock;  // (no host-buffer search on the second lane meanwhile either)
+  {
+    std::lock_guard<std::mutex> lm(ix->lane_mu);
+    if (ix->lane2) lane2_lock = std::unique_lock<std::mutex>(ix->lane2->host_mu);
+  }
   ON_DEVICE(ix->device);
   const int W = ef_construction;
   const uint32_t keep = std::max<uint32_t>(ix->M / 2, 1);  // Index.h:373

@@ -123,6 +123,54 @@ def test_large_host_batches_come_back_through_the_pinned_result_slab(oracle_mod,
     _assert_exact(w2, dev.search(Qa[:3000], 5, 300, stats=True), "ef=300, two heaps")
 
 
+def test_concurrent_host_callers_share_a_handle(oracle_mod, hipmod):
+    # Two (and more) threads in fnv_search_batch on ONE handle: the second caller runs on the handle's hidden second lane
+    # (own stream, workspace, staging; same HBM buffers), a third one waits.  Every caller gets the oracle's bytes for ITS
+    # queries, fnv_tune and a device insertion keep both lanes out while they run, and the lane takes over options set later.
+    import threading
+
+    X, Q = ds.sift_like(20000, 24000)
+    ix = oracle_mod.OracleIndex.create("l2", 128, 20000, 16)
+    ix.add(X, 48)
+    dev = _upload(hipmod, ix)
+    K, ef = 10, 64
+    parts = [Q[i * 6000:(i + 1) * 6000] for i in range(4)]
+    want = [ix.search(p, K, ef, stats=True, threads=8) for p in parts]
+    errors = []
+
+    def caller(i, rounds):
+        try:
+            for _ in range(rounds):
+                _assert_exact(want[i], dev.search(parts[i], K, ef, stats=True), "caller %d" % i)
+        except Exception as exc:  # noqa: BLE001
+            errors.append((i, repr(exc)))
+
+    for n_threads in (2, 4):
+        th = [threading.Thread(target=caller, args=(i, 4)) for i in range(n_threads)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errors, errors
+    # tuning from one thread while others search: exclusive, and afterwards both lanes run the tuned choice
+    th = [threading.Thread(target=caller, args=(i, 6)) for i in (1, 2)]
+    for t in th:
+        t.start()
+    dev.tune(parts[0], K, ef)
+    for t in th:
+        t.join()
+    assert not errors, errors
+    dev.set_option("sorted_beam", 0)  # an option set later reaches the second lane as well
+    th = [threading.Thread(target=caller, args=(i, 3)) for i in (0, 3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    assert dev.launch_geometry()["kernel"] == "two_heaps"
+    dev.close()  # frees the hidden lane first, then the handle
+
+
 def test_adopted_buffers_answer_like_their_owner(oracle_mod, hipmod):
     # fnv_index_adopt: a second, independent handle (own workspace, stream, options) on buffers the first one owns
     X, Q = ds.sift_like(8000, 700)
