@@ -306,11 +306,15 @@ struct fnv_index_s : IndexOptions {
   // take turns; now the second caller runs on a hidden view of the handle (own stream, workspace and staging, the same HBM
   // buffers), so its copies and its launch overlap the first caller's -- the reference's search is callable from several
   // threads at once (bindings.cpp:198-211 runs it under executeInParallel), and two launches in flight are what hides a
-  // launch's ramp and drain.  Created on first contention; freed with the handle.
-  fnv_index_s* lane2 = nullptr;
-  std::mutex lane_mu;            // creation of lane2
-  uint64_t tune_epoch = 0;       // bumped whenever tuner / layouts change: lane2 copies them when its own epoch lags
-  uint64_t lane_epoch = ~0ull, lane_options = ~0ull;  // (on lane2: what it last copied from its owner)
+  // launch's ramp and drain.  Created on first contention; freed with the handle.  Lane 1 takes
+  // any batch (its workspace can be as large as the handle's: 19 GB of visited bitmaps at 50M nodes); lanes 2 ... 7 only
+  // batches of at most kSmallLaneQueries queries (single queries from many threads: their workspaces are kilobytes).
+  static constexpr int kMaxLanes = 8;
+  static constexpr uint64_t kSmallLaneQueries = 1024;
+  fnv_index_s* lanes[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [0] unused
+  std::mutex lane_mu;            // creation of lanes
+  uint64_t tune_epoch = 0;       // bumped whenever tuner / layouts change: a lane copies them when its own epoch lags
+  uint64_t lane_epoch = ~0ull, lane_options = ~0ull;  // (on a lane: what it last copied from its owner)
 };
 
 namespace {
@@ -582,10 +586,10 @@ int fnv_index_info(fnv_index_t ix, uint64_t info[8]) {
 
 int fnv_index_free(fnv_index_t ix) {
   if (!ix) return FNV_OK;
-  if (ix->lane2) {  // the hidden second lane goes first (it counts as a view of this handle)
-    fnv_index_s* l2 = ix->lane2;
-    ix->lane2 = nullptr;
-    (void)fnv_index_free(l2);
+  for (fnv_index_s*& l : ix->lanes) {  // the hidden lanes go first (they count as views of this handle)
+    fnv_index_s* gone = l;
+    l = nullptr;
+    if (gone) (void)fnv_index_free(gone);
   }
   if (ix->n_views.load() > 0)
     return fail(FNV_ERR_INVALID, "fnv_index_free: the index still has live views (fnv_index_view) on its buffers; free them first");
@@ -1261,15 +1265,15 @@ static int check_search_args(fnv_index_t ix, const void* queries, uint64_t nq, i
   return FNV_OK;
 }
 
-// The hidden second lane of a handle (fnv_index_s::lane2): created on first contention.
-static fnv_index_s* second_lane(fnv_index_t ix) {
+// Hidden lane `which` (1 ... kMaxLanes - 1) of a handle (fnv_index_s::lanes): created on first contention.
+static fnv_index_s* hidden_lane(fnv_index_t ix, int which) {
   std::lock_guard<std::mutex> lock(ix->lane_mu);
-  if (!ix->lane2) {
+  if (!ix->lanes[which]) {
     fnv_index_t v = nullptr;
     if (fnv_index_view(ix, &v) != FNV_OK) return nullptr;
-    ix->lane2 = v;
+    ix->lanes[which] = v;
   }
-  return ix->lane2;
+  return ix->lanes[which];
 }
 // The lane answers exactly like its owner: same options, same measured layouts and kernel choice (copied when they changed).
 static void sync_lane(fnv_index_t ix, fnv_index_s* lane) {
@@ -1298,15 +1302,18 @@ int fnv_search_batch(fnv_index_t ix, const void* queries, uint64_t nq, int K, in
   int rc = check_search_args(ix, queries, nq, K, ef_search, num_initializations, out_dist, out_labels);
   if (rc || nq == 0) return rc;
   // one caller at a time per lane (a lane's staging areas, stream and workspace are its caller's for the whole call); a
-  // caller that finds the handle busy takes the second lane, a third one waits for the first
+  // caller that finds the handle busy takes the second lane, a further ones take more lanes when their batches are small, else wait for the first
   fnv_index_s* lane = ix;
   std::unique_lock<std::mutex> host_lock(ix->host_mu, std::try_to_lock);
   if (!host_lock.owns_lock() && !ix->parent) {
-    if (fnv_index_s* l2 = second_lane(ix)) {
-      std::unique_lock<std::mutex> lock2(l2->host_mu, std::try_to_lock);
-      if (lock2.owns_lock()) {
-        lane = l2;
-        host_lock = std::move(lock2);
+    const int usable = nq <= fnv_index_s::kSmallLaneQueries ? fnv_index_s::kMaxLanes : 2;
+    for (int which = 1; which < usable && !host_lock.owns_lock(); which++) {
+      if (fnv_index_s* l = hidden_lane(ix, which)) {
+        std::unique_lock<std::mutex> lock2(l->host_mu, std::try_to_lock);
+        if (lock2.owns_lock()) {
+          lane = l;
+          host_lock = std::move(lock2);
+        }
       }
     }
   }
@@ -1471,11 +1478,12 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
   if (K <= 0 || ef_search <= 0) return fail(FNV_ERR_INVALID, "K and ef_search must be positive");
   if (!queries || nq == 0) return fail(FNV_ERR_INVALID, "fnv_tune needs a batch of queries");
   std::lock_guard<std::mutex> host_lock(ix->host_mu);
-  std::unique_lock<std::mutex> lane2_lock;  // (no host-buffer search on the second lane meanwhile either)
-  {
-    std::lock_guard<std::mutex> lm(ix->lane_mu);
-    if (ix->lane2) lane2_lock = std::unique_lock<std::mutex>(ix->lane2->host_mu);
-  }
+  // (no host-buffer search on the hidden lanes meanwhile either: the existing ones are locked, and none is created -- a caller
+  //  that wants one waits on lane_mu, holding nothing)
+  std::lock_guard<std::mutex> no_new_lanes(ix->lane_mu);
+  std::vector<std::unique_lock<std::mutex>> lane_locks;
+  for (fnv_index_s* l : ix->lanes)
+    if (l) lane_locks.emplace_back(l->host_mu);
   ON_DEVICE(ix->device);
   const size_t qbytes = (size_t)nq * ix->dim * dtype_size(ix->dtype);
   const size_t o_lab = (size_t)nq * K * 4, obytes = 2 * o_lab;
@@ -1709,11 +1717,12 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
   if (evals_out) *evals_out = 0;
   if (count == 0) return FNV_OK;
   std::lock_guard<std::mutex> host_lock(ix->host_mu);
-  std::unique_lock<std::mutex> lane2_lock;  // (no host-buffer search on the second lane meanwhile either)
-  {
-    std::lock_guard<std::mutex> lm(ix->lane_mu);
-    if (ix->lane2) lane2_lock = std::unique_lock<std::mutex>(ix->lane2->host_mu);
-  }
+  // (no host-buffer search on the hidden lanes meanwhile either: the existing ones are locked, and none is created -- a caller
+  //  that wants one waits on lane_mu, holding nothing)
+  std::lock_guard<std::mutex> no_new_lanes(ix->lane_mu);
+  std::vector<std::unique_lock<std::mutex>> lane_locks;
+  for (fnv_index_s* l : ix->lanes)
+    if (l) lane_locks.emplace_back(l->host_mu);
   ON_DEVICE(ix->device);
   const int W = ef_construction;
   const uint32_t keep = std::max<uint32_t>(ix->M / 2, 1);  // Index.h:373

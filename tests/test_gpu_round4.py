@@ -160,6 +160,23 @@ def test_concurrent_host_callers_share_a_handle(oracle_mod, hipmod):
     for t in th:
         t.join()
     assert not errors, errors
+    # single queries from eight threads: up to eight in flight (lanes 2 ... 7 serve batches of <= 1024 queries only)
+    singles = ix.search(Q[:64], K, ef, stats=True)
+
+    def single_caller(i):
+        try:
+            for j in range(i, 64, 8):
+                got = dev.search(Q[j:j + 1], K, ef, stats=True)
+                assert np.array_equal(got[1][0], singles[1][j]) and np.array_equal(got[0][0].view(np.uint32), singles[0][j].view(np.uint32))
+        except Exception as exc:  # noqa: BLE001
+            errors.append((i, repr(exc)))
+
+    th = [threading.Thread(target=single_caller, args=(i,)) for i in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
     dev.set_option("sorted_beam", 0)  # an option set later reaches the second lane as well
     th = [threading.Thread(target=caller, args=(i, 3)) for i in (0, 3)]
     for t in th:

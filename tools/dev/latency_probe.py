@@ -34,3 +34,18 @@ for ef in (50, 100, 200):
             qq = Q[(r * nq) % 1024:(r * nq) % 1024 + nq]
             t0 = time.perf_counter(); dev.search(qq, 10, ef); ts.append(time.perf_counter() - t0); ks.append(dev.last_kernel_ms())
         print("   batch %4d: wall p50 %.3f ms, kernel p50 %.3f ms -> %.0f QPS" % (nq, np.percentile(ts, 50) * 1e3, np.percentile(ks, 50), nq / np.percentile(ts, 50)), flush=True)
+    # the reference's per-query protocol from SEVERAL caller threads on the one handle (round 4: concurrent callers run on
+    # the handle's hidden lanes -- up to 8 single queries in flight -- instead of taking turns)
+    import threading
+    for T in (1, 2, 4, 8, 16):
+        per = 200
+        def worker(t):
+            for i in range(per):
+                dev.search(Q[(t * per + i) % 2048][None, :], 10, ef)
+        worker(0)
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+        t0 = time.perf_counter()
+        for t in th: t.start()
+        for t in th: t.join()
+        wall = time.perf_counter() - t0
+        print("   %2d caller threads x %d single queries: %.0f queries/s (%.3f ms per query per thread)" % (T, per, T * per / wall, wall / per * 1e3), flush=True)
