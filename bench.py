@@ -395,15 +395,20 @@ def run_config(ctx, args, config, main_line):
     # Every NQ-query search this function asks for is counted, so that a kernel trace of this process can find the timed
     # region by position from the END of its full-grid launches (fnv_tune's own launches all come before it):
     # `roofline.trace_position` = {timed: launches of the timed region, after: launches that followed it}.
+    import threading
+
     launches = {"n": 0, "timed_end": 0}
+    launches_lock = threading.Lock()  # (the host entry point is also called from several threads below)
     _sd, _sh = dev.search_device, dev.search
 
     def _count_device(*a, **k):
-        launches["n"] += 1
+        with launches_lock:
+            launches["n"] += 1
         return _sd(*a, **k)
 
     def _count_host(*a, **k):
-        launches["n"] += 1
+        with launches_lock:
+            launches["n"] += 1
         return _sh(*a, **k)
 
     dev.search_device, dev.search = _count_device, _count_host
@@ -573,27 +578,23 @@ def run_config(ctx, args, config, main_line):
             dev.search(Q_rank[(i + 1) % nb], K, EF)
             host_ts.append(time.perf_counter() - t0)
         host_qps = NQ / float(np.median(host_ts))
-        # ... and with TWO caller threads on the one handle (the second caller runs on the handle's second lane: its copies
-        # and its launch overlap the first caller's -- the reference's search is callable from several threads at once)
-        import threading
-
-        def caller(first):
-            for i in range(first, first + 6, 2):
-                dev.search(Q_rank[i % nb], K, EF)
-        caller(0)  # (first contention creates the second lane: outside the timed region)
-        th = [threading.Thread(target=caller, args=(f,)) for f in (0, 1)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        t0 = time.perf_counter()
-        th = [threading.Thread(target=caller, args=(f,)) for f in (0, 1)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        host2_qps = 6 * NQ / (time.perf_counter() - t0)
-        log("[rank 0] host-buffer (PCIe-inclusive) path: %.0f queries/s; two caller threads: %.0f queries/s" % (host_qps, host2_qps))
+        # ... and with two and four caller threads on the one handle (concurrent callers run on the handle's hidden lanes:
+        # their copies and launches overlap -- the reference's search is callable from several threads at once)
+        def callers(T, per):
+            def work(t):
+                for i in range(per):
+                    dev.search(Q_rank[(t + i) % nb], K, EF)
+            th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            return T * per * NQ / (time.perf_counter() - t0)
+        callers(4, 2)  # (first contention creates the lanes and their launch plans: outside the timed regions)
+        host2_qps = callers(2, 8)
+        host4_qps = callers(4, 8)
+        log("[rank 0] host-buffer (PCIe-inclusive) path: %.0f queries/s; two / four caller threads: %.0f / %.0f queries/s" % (host_qps, host2_qps, host4_qps))
     # ---- two batches in flight (rank-local, informational): a second handle on the same HBM buffers (fnv_index_view),
     #      a second stream, launches alternate -- the drain of one launch (its last, slowest queries at falling
     #      occupancy) overlaps the start of the next.  This is the rate a server that always has the next batch ready
@@ -694,6 +695,7 @@ def run_config(ctx, args, config, main_line):
                 "queries_replayed_by_exact_kernel": replay["total"],
                 "host_buffer_qps_pcie_inclusive": round(host_qps),
                 "host_buffer_qps_two_caller_threads": round(host2_qps),
+                "host_buffer_qps_four_caller_threads": round(host4_qps),
                 "index_bytes_in_hbm": index_bytes,
                 "index_fraction_in_infinity_cache": round(min(1.0, INFINITY_CACHE_BYTES / index_bytes), 3),
                 "measured_in_this_run": "value, ms_per_step, recall, roofline.achieved/avg_kernel_ms, gather ceiling, "

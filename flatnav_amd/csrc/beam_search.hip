@@ -307,8 +307,9 @@ struct fnv_index_s : IndexOptions {
   // buffers), so its copies and its launch overlap the first caller's -- the reference's search is callable from several
   // threads at once (bindings.cpp:198-211 runs it under executeInParallel), and two launches in flight are what hides a
   // launch's ramp and drain.  Created on first contention; freed with the handle.  Lane 1 takes
-  // any batch (its workspace can be as large as the handle's: 19 GB of visited bitmaps at 50M nodes); lanes 2 ... 7 only
-  // batches of at most kSmallLaneQueries queries (single queries from many threads: their workspaces are kilobytes).
+  // any batch (its workspace can be as large as the handle's: 19 GB of visited bitmaps at 50M nodes), lanes 2 and 3 too
+  // while such a workspace stays under 2 GB; lanes beyond only batches of at most kSmallLaneQueries queries (single queries
+  // from many threads: their workspaces are kilobytes).
   static constexpr int kMaxLanes = 8;
   static constexpr uint64_t kSmallLaneQueries = 1024;
   fnv_index_s* lanes[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [0] unused
@@ -1306,7 +1307,12 @@ int fnv_search_batch(fnv_index_t ix, const void* queries, uint64_t nq, int K, in
   fnv_index_s* lane = ix;
   std::unique_lock<std::mutex> host_lock(ix->host_mu, std::try_to_lock);
   if (!host_lock.owns_lock() && !ix->parent) {
-    const int usable = nq <= fnv_index_s::kSmallLaneQueries ? fnv_index_s::kMaxLanes : 2;
+    // large batches: two lanes, or four while a lane's launch workspace (per-slot visited bitmaps + candidate spill areas
+    // for a full grid) stays under 2 GB -- measured on 1M x 128 (r4_run18): 7.8 / 10.4 / 11.2 / 11.5 M queries/s from
+    // 1 / 2 / 3 / 4 caller threads with four lanes, 10.4 M from two on; at 10M and 50M nodes a lane's bitmaps alone are
+    // 3.5 GB and 19 GB
+    const uint64_t lane_workspace = 16ull * (uint64_t)ix->num_cus * (ix->capacity / 8 + (uint64_t)ix->spill_entries * 8);
+    const int usable = nq <= fnv_index_s::kSmallLaneQueries ? fnv_index_s::kMaxLanes : lane_workspace <= (2ull << 30) ? 4 : 2;
     for (int which = 1; which < usable && !host_lock.owns_lock(); which++) {
       if (fnv_index_s* l = hidden_lane(ix, which)) {
         std::unique_lock<std::mutex> lock2(l->host_mu, std::try_to_lock);
