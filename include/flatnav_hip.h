@@ -210,8 +210,9 @@ int fnv_set_option(fnv_index_t index, const char* name, int64_t value);
 
 /* Thread safety: fnv_search_batch may be called concurrently on one index: the first caller uses the handle's own
  * stream / workspace / staging, a second concurrent caller runs on a hidden second lane (a view of the handle, created
- * on first contention: its copies and its launch overlap the first caller's -- round 4), batches of at most 1024 queries
- * may use up to six more such lanes (single queries from many threads are in flight together), further callers wait;
+ * on first contention: its copies and its launch overlap the first caller's -- round 4); large batches use up to four
+ * lanes while a lane's launch workspace stays under 2 GB (1M-node indexes), else two; batches of at most 1024 queries
+ * up to eight (single queries from many threads are in flight together); further callers wait;
  * fnv_search_batch_device shares one per-index workspace, so at most one such launch may be in flight per index
  * (launches on the same stream are naturally ordered).  Different indexes are independent.
  *
