@@ -1327,6 +1327,16 @@ int fnv_search_batch(fnv_index_t ix, const void* queries, uint64_t nq, int K, in
   if (lane != ix) sync_lane(ix, lane);
   rc = search_host_enqueue(lane, queries, nq, K, ef_search, num_initializations, out_dist, out_labels, out_count,
                            out_ndist, out_nhops);
+  if (rc == FNV_ERR_NO_DEVICE && lane != ix) {
+    // a lane could not get its workspace (another copy of the per-slot bitmaps and spill areas: 19 GB at 50M nodes): the
+    // call waits for the handle's own lane instead, like any caller did before there were lanes
+    (void)hipGetLastError();
+    host_lock.unlock();  // (never hold a lane while waiting for the handle: fnv_tune takes them in the other order)
+    host_lock = std::unique_lock<std::mutex>(ix->host_mu);
+    lane = ix;
+    rc = search_host_enqueue(ix, queries, nq, K, ef_search, num_initializations, out_dist, out_labels, out_count, out_ndist,
+                             out_nhops);
+  }
   if (rc) return rc;
   rc = search_host_finish(lane);
   if (lane != ix) {  // what fnv_last_launch_info reports for the handle: the most recent call, whichever lane served it
