@@ -1,7 +1,7 @@
 // kernel_inst.hip -- one compilation = the instantiations of ONE kernel family for ONE (element type, metric):
 //   hipcc -c -DFNV_INST_T=float -DFNV_INST_TAG=f32 -DFNV_INST_METRIC=0 -DFNV_INST_MTAG=l2 -DFNV_INST_FAMILY=4 ...
 // families: 0 exact two-heap kernel + entry scan, 3 wiring kernels, 4 merged beam (<= 256 entries in registers),
-// 5 merged beam (<= 64 entries in registers), 6 merged beam (LDS, any width), 7 merged beam (<= 128 in registers).  flatnav_amd/build.py compiles the 30 combinations in parallel and links them with beam_search.hip.
+// 5 merged beam (<= 64 entries in registers), 6 merged beam (LDS, any width), 7 merged beam (<= 128 in registers).  flatnav_amd/build.py compiles the 36 combinations in parallel and links them with beam_search.hip.
 #include <hip/hip_runtime.h>
 
 #include "kernel_table.h"
