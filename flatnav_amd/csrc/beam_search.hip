@@ -791,13 +791,27 @@ static uint32_t lay_out(const fnv_index_s* ix, SearchParams& p, uint32_t slots, 
 // a lone wave issues slowly -- below ~13 resident queries per CU the loss of latency hiding costs more than sending
 // part of the ids to the HBM bitmap (measured: profiles/r1_visited_sizing.md).  So: the largest size <= roomy that
 // still leaves `occupancy_target` queries per CU, but never below visited_floor slots.
+// gfx950 hands LDS out in 1280-byte granules (160 KiB = 128 of them): a workgroup that asks for 7712 bytes holds seven, and
+// a CU keeps 18 such workgroups, not the floor(163840 / 7712) = 21 that hipOccupancyMaxActiveBlocksPerMultiprocessor reports.
+// Measured in round 4 (tools/dev/probes/lds_granule.cpp: resident single-wave workgroups per CU against the dynamic LDS size
+// -- 7680 bytes: 21, 7681: 18; 8960: 18, 8961: 16; 10240: 16, 10241: 14; 32768: 4) after the launch timeline of the uint8 index
+// showed 18 busy slots per CU under a grid of 21 (profiles/r4_launch_timeline.md).
+constexpr uint32_t kLdsGranule = 1280, kLdsPerCu = 160u * 1024u;
+static inline uint32_t lds_allocated(uint32_t lds) { return (lds + kLdsGranule - 1) / kLdsGranule * kLdsGranule; }
+
 static int configure_launch(fnv_index_s* ix, SearchParams& p, kernel_fn kern, int mode, uint32_t* lds_out, int* bpc_out,
                             bool grow_free = true, uint32_t forced_slots = 0) {
-  auto resident = [&](uint32_t lds) -> int {  // query slots one CU can hold with this much LDS each
-    if (lds > 160u * 1024u) return 0;
+  // query slots one CU holds with this much LDS each, as the occupancy API counts them.  The table-size rules below were
+  // calibrated against THIS number in rounds 1-3 and keep using it (same layouts as measured); what a CU really keeps
+  // resident -- `really_resident` -- decides the granule trim at the end.
+  auto resident = [&](uint32_t lds) -> int {
+    if (lds > kLdsPerCu) return 0;
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kern, WAVE, lds) != hipSuccess) n = 0;
     return n;
+  };
+  auto really_resident = [&](uint32_t lds) -> int {  // registers and wave slots: the API; LDS: whole granules
+    return std::min<int>(resident(lds), (int)(kLdsPerCu / lds_allocated(std::max<uint32_t>(lds, 1u))));
   };
   uint32_t lds_bytes;
   if (forced_slots == 0) forced_slots = (uint32_t)ix->visited_slots;
@@ -840,7 +854,7 @@ static int configure_launch(fnv_index_s* ix, SearchParams& p, kernel_fn kern, in
         if (next > (1u << 15)) break;
         SearchParams q = p;
         const uint32_t bytes = lay_out(ix, q, next, mode);
-        if (q.vis_tag16 != p.vis_tag16 || q.vis_slots != next || bytes > 160u * 1024u || resident(bytes) < resident(lds_bytes)) break;
+        if (q.vis_tag16 != p.vis_tag16 || q.vis_slots != next || bytes > kLdsPerCu || resident(bytes) < resident(lds_bytes)) break;
         p = q;
         lds_bytes = bytes;
       }
@@ -850,8 +864,34 @@ static int configure_launch(fnv_index_s* ix, SearchParams& p, kernel_fn kern, in
     return fail(FNV_ERR_INVALID, "ef_search too large for the on-chip beam state (needs " + std::to_string(lds_bytes) +
                                      " bytes of LDS, 163840 available); lower ef_search or the *_slots options");
   HIP_TRY(raise_lds_limit((const void*)kern, ix->device, lds_bytes));
-  int bpc = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, WAVE, lds_bytes));
+  // A layout that ends a few bytes into a granule pays a whole granule per slot for them.  If dropping at most an eighth of
+  // the exact search's LDS heap entries (its overflow continues in the slot's HBM spill area; the heap is sized by rule of
+  // thumb: cand_factor * B + 192) brings the slot one granule down AND that keeps one more query resident, do so
+  // (the uint8 index at ef=52: 7712 -> 7680 bytes, 18 -> 21 slots per CU, +3 % queries/s, profiles/r4_launch_timeline.md).
+  if (ix->cand_slots == 0 && p.cand_slots > (uint32_t)p.B + 1) {
+    const uint32_t lower = lds_allocated(lds_bytes) - kLdsGranule;
+    const uint32_t over = lds_bytes - lower, entries = (over + 7) / 8;
+    if (lower > 0 && entries <= p.cand_slots / 8 && p.cand_slots - entries >= (uint32_t)p.B + 1 && really_resident(lower) > really_resident(lds_bytes)) {
+      SearchParams q = p;
+      q.cand_slots = p.cand_slots - entries;
+      uint32_t bytes = lay_out(ix, q, p.vis_slots, mode);
+      for (int i = 0; i < 2 && bytes > lower && q.cand_slots > (uint32_t)p.B + 2; i++) {  // (16-byte alignment of what follows the heap)
+        q.cand_slots--;
+        bytes = lay_out(ix, q, p.vis_slots, mode);
+      }
+      if (bytes <= lower && q.vis_slots == p.vis_slots && q.vis_tag16 == p.vis_tag16) {
+        p = q;
+        lds_bytes = bytes;
+      }
+    }
+  }
+  // The GRID stays what the occupancy API counts (rounds 1-3), also where that is more than a CU really keeps resident: the
+  // surplus workgroups start when the first slots exit, find the dispenser empty and leave.  Sizing the grid by
+  // `really_resident` was measured (r4_run26 / r4_run28, alternating with this form on one copy of each index) and lost
+  // 0.7-2.9 % wherever the two differ (10M x 768 ef=670: 99.2 vs 96.5 ms; 1M x 128 ef=100: 1.887 vs 1.864): the exact tail
+  // is a percentage of the grid, and 75 % of the API's count (82 % of the resident slots) happens to sit nearer the best
+  // tail length than 75 % or 100 % of the resident slots do.  (profiles/r4_launch_timeline.md)
+  int bpc = resident(lds_bytes);
   if (bpc < 1) bpc = 1;
   if (ix->blocks_per_cu > 0) bpc = std::min<int>(bpc, (int)ix->blocks_per_cu);
   *lds_out = lds_bytes;

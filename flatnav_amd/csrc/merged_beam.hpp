@@ -126,6 +126,9 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : R == MB_R ? 3 : waves_per_simd<
     asm volatile("" : "+v"(lane));
     const int item = next_query(lane);
     if (item < 0) break;
+#ifdef FNV_TIMELINE  // developer build (tools/dev/launch_timeline.py): the per-query counters carry start / end clock readings instead
+    const unsigned long long tl_start = wall_clock64();
+#endif
     // shadows (search_params.h): items >= shadow_base are exact searches of the LAST queries, most recent first
     const uint32_t shadow_base = cold_args()->shadow_base;
     const bool shadow = shadow_base != 0u && (uint32_t)item >= shadow_base;
@@ -563,6 +566,12 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : R == MB_R ? 3 : waves_per_simd<
       x.stage_ids = reinterpret_cast<uint32_t*>(smem + xa->off_stage_ids);
       x.ovf_list = reinterpret_cast<uint32_t*>(smem + xa->off_ovf);
       exact_query<T, METRIC, G, CU, FULL>(x, q, qi, entry, best_d, lane, ph, shadow ? xa->done_flags + qi : nullptr);
+#ifdef FNV_TIMELINE  // bits 60-61 of the end reading: 1 = searched twice (equal keys), 2 = sent straight to the exact search
+      if (lane == 0 && !shadow && xa->out_ndist && xa->out_nhops) {
+        xa->out_ndist[qi] = tl_start;
+        xa->out_nhops[qi] = wall_clock64() | ((unsigned long long)(tie == 5 ? 2 : 1) << 60);
+      }
+#endif
       PH_FLUSH;
       continue;
     } else {
@@ -590,8 +599,13 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : R == MB_R ? 3 : waves_per_simd<
       }
       if (lane == 0) {
         if (c->out_count) c->out_count[qi] = cnt;
+#ifdef FNV_TIMELINE
+        if (c->out_ndist) c->out_ndist[qi] = tl_start;
+        if (c->out_nhops) c->out_nhops[qi] = wall_clock64();
+#else
         if (c->out_ndist) c->out_ndist[qi] = n_dist;
         if (c->out_nhops) c->out_nhops[qi] = n_hops;
+#endif
         // answered: a shadow stops / never starts (it writes the same bytes if it gets there first, so no ordering is needed)
         if (shadow_base != 0u) __hip_atomic_store(c->done_flags + qi, SH_ANSWERED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
