@@ -587,6 +587,40 @@ int orc_search(void* h, const void* queries, uint64_t nq, int K, int ef, int n_i
   ORC_CATCH
 }
 
+// The reference's `neighbors` heap driven by a LOG of evaluated neighbours instead of a traversal: entry 0 is the entry
+// point, then every evaluated neighbour (distance, node id) in evaluation order.  Admission (Index.h:693-704) and result
+// assembly (Index.h:393-408) are the reference's, on the real std::priority_queue / std::sort.  Used by
+// tests/test_replay_model.py (a design check for the GPU path: when the merged-beam kernel's traversal is known to be the
+// reference's and only the ORDER of equal distances among the results is open, replaying its log decides it).
+int orc_replay_neighbors(const float* d, const uint32_t* ids, uint64_t n, int buffer_size, int K, float* out_d,
+                         uint32_t* out_ids, int32_t* out_count) {
+  ORC_TRY
+  if (n == 0 || K <= 0 || buffer_size <= 0) throw std::invalid_argument("empty log");
+  PriorityQueue neighbors;
+  neighbors.emplace(d[0], ids[0]);
+  float max_dist = d[0];
+  for (uint64_t i = 1; i < n; i++) {
+    if (neighbors.size() < (size_t)buffer_size || d[i] < max_dist) {
+      neighbors.emplace(d[i], ids[i]);
+      if (neighbors.size() > (size_t)buffer_size) neighbors.pop();
+      if (!neighbors.empty()) max_dist = neighbors.top().first;
+    }
+  }
+  std::vector<dist_node_t> results;
+  while (!neighbors.empty()) {
+    results.push_back(neighbors.top());
+    neighbors.pop();
+  }
+  std::sort(results.begin(), results.end(), [](const dist_node_t& l, const dist_node_t& r) { return l.first < r.first; });
+  if (results.size() > (size_t)K) results.resize(K);
+  for (size_t k = 0; k < results.size(); k++) {
+    out_d[k] = results[k].first;
+    out_ids[k] = results[k].second;
+  }
+  *out_count = (int32_t)results.size();
+  ORC_CATCH
+}
+
 int orc_save(void* h, const char* path) {
   ORC_TRY
   save_index(*(Index*)h, path);

@@ -53,6 +53,8 @@ def lib() -> C.CDLL:
         L.orc_search.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int] + [
             C.c_void_p
         ] * 7
+        L.orc_replay_neighbors.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.POINTER(C.c_int32)]
         L.orc_save.argtypes = [C.c_void_p, C.c_char_p]
         L.orc_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
         L.orc_from_blob.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
@@ -206,6 +208,17 @@ class OracleIndex:
 
     def save(self, path: str) -> None:
         _check(lib().orc_save(self._h, path.encode()))
+
+
+def replay_neighbors(dists, ids, buffer_size: int, K: int):
+    """The reference's neighbours heap and result assembly (Index.h:693-704, 393-408) driven by a log of evaluated
+    neighbours -- entry point first, then (distance, node id) in evaluation order.  Returns (float32[<=K], uint32[<=K])."""
+    d = np.ascontiguousarray(dists, dtype=np.float32)
+    i = np.ascontiguousarray(ids, dtype=np.uint32)
+    od, oi, cnt = np.empty(K, dtype=np.float32), np.empty(K, dtype=np.uint32), C.c_int32(0)
+    _check(lib().orc_replay_neighbors(d.ctypes.data, i.ctypes.data, len(d), buffer_size, K, od.ctypes.data, oi.ctypes.data,
+                                      C.byref(cnt)))
+    return od[:cnt.value], oi[:cnt.value]
 
 
 def distance(metric: str, x: np.ndarray, y: np.ndarray) -> float:
