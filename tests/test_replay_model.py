@@ -39,7 +39,7 @@ def model_search(X, links, q, K, ef, n_init=100):
     n = len(X)
     B = max(ef, K)
     step = max(1, n // n_init)
-    best, entry = np.float32(np.finfo(np.float32).max), 0
+    best, entry = np.float32(3.4028234663852886e38), 0  # FLT_MAX
     for node in range(0, n, step):  # Index.h:845-870: first minimum wins
         d = _l2(q, X[node])
         if d < best:
