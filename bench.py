@@ -16,16 +16,19 @@ Configurations (BASELINE.json `configs`, generators of SURVEY.md 8d; no dataset 
 All with M=32, ef_construction=100, K=10.  The metric's rule: the smallest ef of the sweep with recall@10 >= 0.95,
 recall measured on all 10 000 queries of the first batch against exact brute force.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel; achieved =
-algorithmic bytes per launch / average launch duration from HIP events on the launch stream; `gather_ceiling` = what a
-pure random-row gather of this very vector table reaches, measured in the run), `cpu_baseline` (N=1: the CPU oracle
-timed on the host cores), `secondary` (fixed-ef lines of the main configuration + one summary per further configuration)
-and `sustained` (>= 1 s of back-to-back steps).  The value, metric and config of the line are the main configuration's
-(c2 by default).  FURTHER CONFIGURATIONS -- like the reference's harness, which runs a list of datasets and ef values in
-one invocation (experiments/run-benchmark.py:362-506, tools/query_npy.cpp:132-158) -- run after it in the same process
-and land as full entries (own recall / ef rule, roofline, counters, cpu_baseline with GPU ids == CPU ids) under the
-top-level keys "c4", "c3-lowrank", "c5", "c5-lowrank" (N = 1; with N > 1 GPUs only "c5", the configuration that is
-worded for 8 GPUs); `--secondary-configs none` turns them off, `--time-budget` skips what no longer fits.
+Output (round 5).  stdout carries exactly ONE line, printed last by rank 0: the contract line of the main configuration
+(c2 by default), at most 4 KB -- contract fields, `roofline` (dominant kernel; achieved = algorithmic bytes per launch /
+average launch duration from HIP events on the launch stream; `gather_ceiling` = what a pure random-row gather of this very
+vector table reaches, measured in the run), `cpu_baseline` (N=1: the CPU oracle timed on the host cores),
+`value_pcie_inclusive` (the same search through the host-buffer entry point: SURVEY 8d's definition of the metric),
+`timed_regions` (value = the median of --regions timed regions of --steps launches each; min / max beside it) and
+`secondary`: one short row per fixed-ef line and per FURTHER CONFIGURATION.  Those run after the main one in the same
+process -- like the reference's harness, which runs a list of datasets and ef values in one invocation
+(experiments/run-benchmark.py:362-506, tools/query_npy.cpp:132-158) -- N = 1: c2-uint8, c4, c3-lowrank, c3, c5, c5-lowrank;
+N > 1 GPUs: only c5, the configuration worded for 8 GPUs; `--secondary-configs none` turns them off, `--time-budget` skips
+what no longer fits.  The FULL record -- every configuration's whole entry (own recall / ef rule, roofline, counters,
+cpu_baseline with GPU ids == CPU ids, sustained and two-launches-in-flight rates, per-rank and broadcast reports) -- is
+written to bench_out/bench_full.json (`--full-record`) and, as one line, to stderr.
 Multi-GPU: one process per GPU; `--gpus N` without a torch.distributed environment spawns the N ranks itself.
 Index replicated with one RCCL broadcast per buffer at load, queries sharded, no per-query collective; weak scaling.
 """
@@ -116,6 +119,9 @@ def parse_args():
                          "top-level key (default: c4,c3-lowrank,c5,c5-lowrank on one GPU, c5 on several; 'none' = off)")
     ap.add_argument("--secondary-index-size", type=int, default=0,
                     help="node count of the secondary configurations (0 = each configuration's own; tests use small ones)")
+    ap.add_argument("--full-record", default="", help="where the full record goes (default: bench_out/bench_full.json)")
+    ap.add_argument("--regions", type=int, default=3,
+                    help="timed regions of --steps launches each per configuration; value = the median region's (min / max reported)")
     ap.add_argument("--time-budget", type=float, default=1500.0,
                     help="seconds after which no further secondary configuration is started")
     return ap.parse_args()
@@ -289,13 +295,132 @@ def main() -> None:
         dist.destroy_process_group()
     if rank == 0:
         out["bench_wall_seconds"] = round(time.time() - t_start, 1)
-        # LAST key of the line (round 4): one short row per configuration, so that whatever tail of this (long) line a log
-        # keeps still names every configuration with its ef, recall, queries/s, roofline fraction and CPU baseline.
         rows = [summary_row(args.config, out)] + [summary_row(n, out[n]) for n in names if isinstance(out.get(n), dict)]
         out["summary"] = rows
         for r in rows:
             log("[bench] " + r)
-        print(json.dumps(compact(out), separators=(",", ":")), flush=True)
+        # Round 5: the FULL record (every configuration's whole entry: ~25 KB) goes to a file and to stderr; stdout carries
+        # ONE line, last, of at most CONTRACT_LINE_MAX bytes -- the contract fields of the main configuration with `roofline`
+        # and `cpu_baseline`, and one short row per further configuration (round 4's single 25 KB line was not parsed by
+        # the driver).  The reference's harness likewise writes a small machine-readable metrics record
+        # (experiments/run-benchmark.py:329-343).
+        full_path = write_full_record(compact(out), args.full_record)
+        print(contract_line(out, names, args.config, full_path), flush=True)
+
+
+CONTRACT_LINE_MAX = 4096  # bytes; the driver parses the last stdout line, a 15 KB one still parsed, a 25 KB one did not
+
+
+def write_full_record(full, path):
+    """The whole record as pretty JSON: to `path` (default bench_out/bench_full.json under the repository, best effort --
+    a read-only tree must not cost the contract line) and, as one line, to stderr."""
+    log("[bench] full record: " + json.dumps(full, separators=(",", ":")))
+    path = path or os.path.join(ROOT, "bench_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        return os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT + os.sep) else path
+    except OSError as exc:
+        log("[bench] could not write %s: %s" % (path, exc))
+        return None
+
+
+def _sig(x, digits=5):
+    """Floats of the short rows: `digits` significant digits (the contract's own value / ms_per_step keep every digit)."""
+    if isinstance(x, float) and x == x and abs(x) not in (0.0, float("inf")):
+        return float("%.*g" % (digits, x))
+    return x
+
+
+def contract_line(out, names, main_name, full_path):
+    """The ONE stdout line: contract fields + roofline + cpu_baseline of the main configuration, `value_pcie_inclusive`
+    (SURVEY 8d defines the metric on the call that includes the copies), the three timed regions behind `value`, and one
+    short row per further configuration.  Never longer than CONTRACT_LINE_MAX bytes: optional parts are dropped, in a
+    fixed order, until it fits (a CPU test builds a seven-configuration record and checks the size)."""
+    c, r = out["config"], out["roofline"]
+    launch = c.get("launch") or {}
+    traffic_rec = (r.get("traffic_recorded") or {}).get("hbm_bytes_per_launch_corrected")
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {
+        "workload": c["workload"][:320],
+        "ef_search": c["ef_search"],
+        "recall_at_10": c["recall_at_10"],
+        "recall_min_over_timed_batches": c["recall_all_timed_batches"]["min"],
+        "timed_batches": c["recall_all_timed_batches"]["batches"],
+        "parallelism": c["parallelism"],
+        "kernel_variant": c.get("kernel_variant"),
+        "exploratory_timed_launches": c.get("exploratory_timed_launches"),
+        "queries_replayed_by_exact_kernel": c.get("queries_replayed_by_exact_kernel"),
+        "queries_straight_to_exact_kernel": launch.get("tail_exact"),
+        "launch": {k: launch.get(k) for k in ("kernel", "grid_blocks", "blocks_per_cu", "resident_per_cu", "lds_bytes", "visited_slots") if k in launch},
+    }
+    line["roofline"] = {
+        "bound": r["bound"], "kernel": r["kernel"], "achieved": _sig(r["achieved"], 6), "peak": r["peak"], "unit": r["unit"],
+        "frac": _sig(r["frac"], 6), "gather_ceiling": _sig(r.get("gather_ceiling"), 6),
+        "frac_of_gather_ceiling": _sig(r.get("frac_of_gather_ceiling"), 4),
+        "algorithmic_bytes_per_launch": _sig(r["algorithmic_bytes_per_launch"], 7), "avg_kernel_ms": _sig(r["avg_kernel_ms"], 6),
+        "traffic": r.get("traffic"),
+        "traffic_recorded": traffic_rec,
+        "traffic_over_algorithmic": None if not traffic_rec else _sig(traffic_rec / r["algorithmic_bytes_per_launch"], 3),
+    }
+    cpu = out.get("cpu_baseline")
+    if cpu:
+        line["cpu_baseline"] = {"value": _sig(cpu["value"], 6), "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"],
+                                "sample": cpu.get("sample_short") or cpu["sample"][:160]}
+    line["value_pcie_inclusive"] = c.get("host_buffer_qps_pcie_inclusive")
+    line["timed_regions"] = {k: (_sig(v) if not isinstance(v, list) else [_sig(x, 4) for x in v])
+                             for k, v in (out.get("timed_regions") or {}).items() if k != "note"} or None
+    if out.get("pipelined"):
+        line["two_launches_in_flight"] = _sig(out["pipelined"]["value"])
+    mg = c.get("multi_gpu")
+    if mg:  # three numbers; per-rank lists, the broadcast report and the peer matrix are in the full record
+        rates = mg.get("per_rank_queries_per_s") or [0.0]
+        gbps = [b.get("GBps") or 0.0 for b in (mg.get("index_broadcast") or [])]
+        line["multi_gpu"] = {"slowest_rank_qps": _sig(min(rates)), "fastest_rank_qps": _sig(max(rates)),
+                             "index_broadcast_GBps_min": _sig(min(gbps)) if gbps else None}
+    sec = []
+    for e2 in out.get("secondary", []):
+        if "config" not in e2:  # a fixed-ef line of the main configuration
+            sec.append({"config": main_name, "ef": e2["ef_search"], "recall": e2.get("recall_at_10"), "value": _sig(e2["value"]),
+                        "frac": _sig(e2.get("roofline_frac"), 3)})
+            continue
+        e = out.get(e2["config"]) or {}
+        if e2.get("skipped") or "skipped" in e:
+            sec.append({"config": e2["config"], "skipped": str(e.get("skipped", e2.get("error", True)))[:80]})
+            continue
+        cpu2 = e.get("cpu_baseline")
+        reg = e.get("timed_regions") or {}
+        sec.append({"config": e2["config"], "ef": e["config"]["ef_search"], "recall": e["config"]["recall_at_10"],
+                    "recall_min": e["config"]["recall_all_timed_batches"]["min"], "value": _sig(e["value"]),
+                    "min": _sig(reg.get("min")), "max": _sig(reg.get("max")),
+                    "frac": _sig(e["roofline"]["frac"], 3), "kernel_ms": _sig(e["roofline"]["avg_kernel_ms"], 4),
+                    "pcie": e["config"].get("host_buffer_qps_pcie_inclusive"),
+                    "cpu": None if not cpu2 else _sig(cpu2["value"], 4)})
+    line["secondary"] = sec
+    line["bench_wall_seconds"] = out.get("bench_wall_seconds")
+    line["full_record"] = full_path
+    # what may go, in this order, if a line ever grows past the limit
+    droppable = [("roofline", "traffic_over_algorithmic"), ("config", "launch"), ("config", "parallelism"), ("cpu_baseline", "sample"),
+                 (None, "two_launches_in_flight"), (None, "timed_regions"), (None, "multi_gpu")]
+    text = json.dumps(line, separators=(",", ":"))
+    while len(text.encode()) > CONTRACT_LINE_MAX:
+        if droppable:
+            parent, key = droppable.pop(0)
+            (line if parent is None else line.get(parent, {})).pop(key, None)
+        elif any(len(row) > 3 for row in line["secondary"]):
+            for row in line["secondary"]:  # rows shrink to config / value / frac
+                for k in [k for k in row if k not in ("config", "value", "frac", "skipped")]:
+                    row.pop(k)
+        elif line["secondary"]:
+            line["secondary"].pop()
+        else:
+            line["config"]["workload"] = line["config"]["workload"][:100]
+            text = json.dumps(line, separators=(",", ":"))
+            break
+        text = json.dumps(line, separators=(",", ":"))
+    return text
 
 
 def peer_matrix(world):
@@ -406,7 +531,7 @@ def run_config(ctx, args, config, main_line):
     # `roofline.trace_position` = {timed: launches of the timed region, after: launches that followed it}.
     import threading
 
-    launches = {"n": 0, "timed_end": 0}
+    launches = {"n": 0, "timed_end": 0, "timed_open": False}
     launches_lock = threading.Lock()  # (the host entry point is also called from several threads below)
     _sd, _sh = dev.search_device, dev.search
 
@@ -527,8 +652,8 @@ def run_config(ctx, args, config, main_line):
                 break
         barrier()
         elapsed = time.perf_counter() - t0
-        if launches["timed_end"] is None:
-            launches["timed_end"] = launches["n"]  # (the main measurement's timed region ends here)
+        if launches["timed_end"] is None or launches["timed_open"]:
+            launches["timed_end"] = launches["n"]  # (the main measurement's last timed region ends here)
         dev.status()
         per_rank.clear()
         if dist is not None:
@@ -557,16 +682,28 @@ def run_config(ctx, args, config, main_line):
             nhs.append(nh.mean())
         return tot / len(batches), tot_rows / len(batches), float(np.mean(nds)), float(np.mean(nhs))
 
-    def measure(ef, steps, warmup, min_seconds=0.0):
-        elapsed, kms, done, explored = run(ef, steps, warmup, min_seconds)
+    def measure(ef, steps, warmup, min_seconds=0.0, regions=1):
+        """`regions` timed regions of `steps` launches each (each bracketed by its own barriers; the warm-up precedes the
+        first); the numbers are the MEDIAN region's, `regions_qps` lists all of them (round 5: one region of 10-20 launches
+        is 10-20 ms -- box-to-box and run-to-run differences of 5-10 % were larger than what a round gained)."""
+        runs = []
+        for g in range(max(1, regions)):
+            elapsed, kms, done, explored = run(ef, steps, warmup if g == 0 else 0, min_seconds)
+            runs.append((NQ * world * done / elapsed, elapsed, kms, done, explored, list(per_rank)))
+        order = sorted(range(len(runs)), key=lambda j: runs[j][0])
+        qps, elapsed, kms, done, explored, pr = runs[order[len(order) // 2]]
+        per_rank[:] = pr
         used = sorted(set(i % nb for i in range(done)))
         byts, row_byts, nd_mean, nh_mean = launch_bytes(ef, used[:8])
         avg_kernel_s = float(np.mean(kms)) / 1e3
-        return dict(elapsed=elapsed, steps=done, qps=NQ * world * done / elapsed, bytes=byts, row_bytes=row_byts, nd=nd_mean,
-                    nh=nh_mean, kernel_ms=avg_kernel_s * 1e3, achieved=byts / avg_kernel_s / 1e9, explored=explored)
+        return dict(elapsed=elapsed, steps=done, qps=qps, bytes=byts, row_bytes=row_byts, nd=nd_mean,
+                    nh=nh_mean, kernel_ms=avg_kernel_s * 1e3, achieved=byts / avg_kernel_s / 1e9,
+                    explored=sum(r[4] for r in runs), regions_qps=[r[0] for r in runs],
+                    regions_kernel_ms=[float(np.mean(r[2])) for r in runs])
 
-    launches["timed_end"] = None
-    main_m = measure(EF, args.steps, args.warmup)
+    launches["timed_end"], launches["timed_open"] = None, True
+    main_m = measure(EF, args.steps, args.warmup, regions=args.regions)
+    launches["timed_open"] = False
     main_per_rank = list(per_rank)
     out = None
     if rank == 0:
@@ -704,6 +841,7 @@ def run_config(ctx, args, config, main_line):
                 "kernel_choice": "fnv_tune: every variant measured on batch 0 in one explicit call before the warm-up "
                                  "(%.3f s); timed launches that were exploratory samples of the adaptive choice: %d"
                                  % (tuned.get(EF, 0.0), main_m["explored"]),
+                "exploratory_timed_launches": main_m["explored"],
                 "queries_replayed_by_exact_kernel": replay["total"],
                 "host_buffer_qps_pcie_inclusive": round(host_qps),
                 "host_buffer_qps_two_caller_threads": round(host2_qps),
@@ -735,8 +873,13 @@ def run_config(ctx, args, config, main_line):
                 "line_bytes_per_launch": main_m["row_bytes"],
                 "achieved_line_GBps": main_m["row_bytes"] / (main_m["kernel_ms"] / 1e3) / 1e9,
                 "avg_kernel_ms": main_m["kernel_ms"],
-                "trace_position": {"timed": args.steps, "after": None},  # filled in below, once every launch has been made
+                # the main measurement's timed regions are back to back in a kernel trace but for the launches that read
+                # the counters after each of them; filled in below, once every launch has been made
+                "trace_position": {"timed": args.steps, "regions": max(1, args.regions), "after": None},
             },
+            "timed_regions": {"n": len(main_m["regions_qps"]), "min": min(main_m["regions_qps"]), "median": main_m["qps"],
+                              "max": max(main_m["regions_qps"]), "kernel_ms": main_m["regions_kernel_ms"],
+                              "note": "value / ms_per_step / roofline are the median region's (each region: --steps launches)"},
             "secondary": secondary,
             "sustained": sustained,
             "pipelined": pipelined,
@@ -862,6 +1005,8 @@ def cpu_baseline(index, dev, Q, K, EF, hw, dtype, metric, seconds=8.0):
         "unit": "queries/s",
         "cores": threads,
         "kind": "port",
+        "sample_short": "%d x first %d queries of batch 0, %d threads (1 thread: %.0f q/s); GPU ids == CPU ids on %.2f%% of them; %s"
+                        % (reps, sample, threads, qps1, same * 100, "reference's AVX-512 distance kernel" if "oracle/_ref" in kind_note else "own AVX2 distance"),
         "sample": "%d x the first %d queries of batch 0 on %d host threads (%s); single-thread: %.0f queries/s; "
                   "GPU ids == CPU ids on %.2f%% of the sample; host: %s, %d CPUs visible, %d usable (cgroup quota)"
                   % (reps, sample, threads, kind_note, qps1, same * 100, cpu_model, os.cpu_count() or 0, hw),

@@ -266,7 +266,8 @@ struct fnv_index_s : IndexOptions {
   int last_variant = 0;          // what the most recent launch ran: 0 two-heap kernel, 1 merged beam, 2-4 with exact tail
   bool last_exploratory = false;  // ... and whether the adaptive choice was still sampling (not its final pick)
   bool last_shadow = false;       // ... and whether every query had an exact shadow (small launches)
-  uint64_t t_enqueue_ns = 0, t_complete_ns = 0;  // host-buffer searches: steady-clock time of launch / of completion
+  // host-buffer searches: steady-clock time of launch / of completion (atomic: every lane's caller reports into the handle)
+  std::atomic<uint64_t> t_enqueue_ns{0}, t_complete_ns{0};
   // workspace (grown on demand)
   uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status, [3] queries a merged-beam launch searched exactly, [4..7] by reason
   unsigned long long* d_phase = nullptr;  // profiling builds only
@@ -306,13 +307,19 @@ struct fnv_index_s : IndexOptions {
   // take turns; now the second caller runs on a hidden view of the handle (own stream, workspace and staging, the same HBM
   // buffers), so its copies and its launch overlap the first caller's -- the reference's search is callable from several
   // threads at once (bindings.cpp:198-211 runs it under executeInParallel), and two launches in flight are what hides a
-  // launch's ramp and drain.  Created on first contention; freed with the handle.  Lane 1 takes
-  // any batch (its workspace can be as large as the handle's: 19 GB of visited bitmaps at 50M nodes), lanes 2 and 3 too
-  // while such a workspace stays under 2 GB; lanes beyond only batches of at most kSmallLaneQueries queries (single queries
-  // from many threads: their workspaces are kilobytes).
+  // launch's ramp and drain.  Created on first contention; freed with the handle.
+  // Round 5: EVERY lane is admitted by the HBM its launch workspace would really take (lane_workspace_bytes: slots x (visited
+  // bitmap + overflow list + candidate spill area) for this batch size and the plan's residency) against a budget for all
+  // hidden lanes together -- an eighth of the device's memory (36 GB of 288): one full-grid lane at 50M nodes (19 GB), three
+  // at 10M, all seven at 1M; 1024-query batches at 50M nodes cost 6.4 GB each, so five of those.  A lane that does not fit
+  // is not used (the caller waits for the handle, as before lanes existed); an idle lane's workspace is released when the
+  // budget or the owner's own allocation needs the room (release_idle_lanes).
   static constexpr int kMaxLanes = 8;
-  static constexpr uint64_t kSmallLaneQueries = 1024;
-  fnv_index_s* lanes[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [0] unused
+  bool is_lane = false;          // a hidden lane: never samples or explores (it copies the owner's measurements)
+  std::atomic<uint64_t> explored_launches{0};  // launches that were exploratory samples of the adaptive choice
+  std::atomic<size_t> ws_bytes{0};  // launch workspace this handle holds (visited bitmaps + overflow lists + spill areas)
+  size_t lane_budget_bytes = 0;  // owner: budget for the hidden lanes' workspaces together (set at creation)
+  std::atomic<fnv_index_s*> lanes[kMaxLanes] = {};  // [0] unused; written under lane_mu, read anywhere
   std::mutex lane_mu;            // creation of lanes
   uint64_t tune_epoch = 0;       // bumped whenever tuner / layouts change: a lane copies them when its own epoch lags
   uint64_t lane_epoch = ~0ull, lane_options = ~0ull;  // (on a lane: what it last copied from its owner)
@@ -324,6 +331,13 @@ int index_common_init(fnv_index_s* ix) {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, ix->device));
   ix->num_cus = prop.multiProcessorCount;
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = 0;
+    (void)hipGetLastError();
+    ix->lane_budget_bytes = total_b / 8;
+    if (const char* env = getenv("FLATNAV_LANE_BUDGET_MB")) ix->lane_budget_bytes = (size_t)strtoull(env, nullptr, 10) << 20;
+  }
   HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&ix->ev0));
   HIP_TRY(hipEventCreate(&ix->ev1));
@@ -426,7 +440,7 @@ int write_nodes_impl(fnv_index_s* ix, uint64_t first_node, uint64_t count_nodes,
 extern "C" {
 
 const char* fnv_last_error(void) { return g_err.c_str(); }
-const char* fnv_version(void) { return "flatnav_hip gfx950 r4"; }
+const char* fnv_version(void) { return "flatnav_hip gfx950 r5"; }
 
 int fnv_device_count(int* count) {
   if (!count) return fail(FNV_ERR_INVALID, "count is null");
@@ -587,9 +601,8 @@ int fnv_index_info(fnv_index_t ix, uint64_t info[8]) {
 
 int fnv_index_free(fnv_index_t ix) {
   if (!ix) return FNV_OK;
-  for (fnv_index_s*& l : ix->lanes) {  // the hidden lanes go first (they count as views of this handle)
-    fnv_index_s* gone = l;
-    l = nullptr;
+  for (std::atomic<fnv_index_s*>& l : ix->lanes) {  // the hidden lanes go first (they count as views of this handle)
+    fnv_index_s* gone = l.exchange(nullptr);
     if (gone) (void)fnv_index_free(gone);
   }
   if (ix->n_views.load() > 0)
@@ -668,6 +681,10 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   std::string n(name);
   if (value < 0 && !((n == "sorted_tail_exact_pct" || n == "sorted_variant") && value == -1))
     return fail(FNV_ERR_INVALID, "option values must be non-negative");
+  // Under the handle's mutex (round 5): a launch reads the options, the tuner and the layouts under it, and a concurrent
+  // caller's lane copies them under it (sync_lane) -- an option may change while other threads search; each launch sees the
+  // options either before or after the change.
+  std::lock_guard<std::mutex> lock(ix->mu);
   if (n == "visited_factor") ix->visited_factor = std::max<int64_t>(1, value);
   else if (n == "visited_slots") {
     if (value && (value & (value - 1)) && ((value % 3) || ((value / 3) & (value / 3 - 1))))
@@ -716,14 +733,14 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
 static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq, int K, int ef_search,
                               int num_initializations, float* d_out_dist, int32_t* d_out_labels, int32_t* d_out_count,
                               uint64_t* d_out_ndist, uint64_t* d_out_nhops, void* hip_stream, bool node_ids,
-                              int force_variant = -1);
+                              int force_variant = -1, bool ids_by_option = false);
 
 int fnv_search_batch_device(fnv_index_t ix, const void* d_queries, uint64_t nq, int K, int ef_search,
                             int num_initializations, float* d_out_dist, int32_t* d_out_labels,
                             int32_t* d_out_count, uint64_t* d_out_ndist, uint64_t* d_out_nhops, void* hip_stream) {
   if (!ix) return fail(FNV_ERR_INVALID, "index is null");
   return search_device_impl(ix, d_queries, nq, K, ef_search, num_initializations, d_out_dist, d_out_labels, d_out_count,
-                            d_out_ndist, d_out_nhops, hip_stream, ix->output_node_ids != 0);
+                            d_out_ndist, d_out_nhops, hip_stream, false, -1, /*ids_by_option=*/true);
 }
 
 // ---- launch configuration ---------------------------------------------------------------------------------
@@ -910,11 +927,50 @@ static int grow(void** buf, size_t* have, size_t need, bool zero = false) {
   return FNV_OK;
 }
 
+// Frees the launch workspace of every hidden lane of `ix` that is idle right now (nobody inside a call on it), except
+// `keep`; returns the bytes released.  Never blocks: a lane in use, or a handle whose lanes are being created / held by
+// fnv_tune, is left alone.  The lanes re-grow on their next call.
+static size_t release_idle_lanes(fnv_index_s* ix, const fnv_index_s* keep) {
+  std::unique_lock<std::mutex> lanes_lock(ix->lane_mu, std::try_to_lock);
+  if (!lanes_lock.owns_lock()) return 0;
+  size_t freed = 0;
+  for (std::atomic<fnv_index_s*>& slot : ix->lanes) {
+    fnv_index_s* l = slot.load();
+    if (!l || l == keep) continue;
+    std::unique_lock<std::mutex> idle(l->host_mu, std::try_to_lock);
+    if (!idle.owns_lock()) continue;
+    std::lock_guard<std::mutex> lk(l->mu);
+    DeviceScope scope(l->device);
+    void** bufs[] = {(void**)&l->d_bitmap, (void**)&l->d_ovf, (void**)&l->d_spill};
+    size_t* sizes[] = {&l->bitmap_bytes, &l->ovf_bytes, &l->spill_bytes};
+    for (int i = 0; i < 3; i++) {
+      if (*bufs[i]) (void)hipFree(*bufs[i]);
+      *bufs[i] = nullptr;
+      freed += *sizes[i];
+      *sizes[i] = 0;
+    }
+    l->ws_bytes = 0;
+  }
+  (void)hipGetLastError();
+  return freed;
+}
+
+// HBM a launch of `nq` queries needs as per-slot workspace on a handle of this index (what search_device_impl grows).
+static size_t launch_workspace_bytes(fnv_index_s* ix, uint64_t nq) {
+  std::lock_guard<std::mutex> lock(ix->mu);
+  const uint64_t bitmap_words = ((ix->capacity + 31) / 32 + 3) / 4 * 4;
+  const uint64_t ovf_cap = ix->overflow_list >= 0 ? (uint64_t)ix->overflow_list : (bitmap_words * 4 > (512u << 10) ? 16384u : 0u);
+  const int per_cu = ix->plan.valid ? std::max(ix->plan.bpc, ix->plan.sbpc) : 32;  // (no plan yet: the hardware's 32 waves per CU)
+  const uint64_t slots = std::min<uint64_t>(2 * nq, (uint64_t)per_cu * (uint64_t)ix->num_cus);  // (small launches: a shadow per query)
+  return (size_t)(slots * (bitmap_words * 4 + ovf_cap * 4 + (uint64_t)ix->spill_entries * 8));
+}
+
 static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq, int K, int ef_search,
                               int num_initializations, float* d_out_dist, int32_t* d_out_labels, int32_t* d_out_count,
                               uint64_t* d_out_ndist, uint64_t* d_out_nhops, void* hip_stream, bool node_ids,
-                              int force_variant) {  // >= 0: fnv_tune's launches (an argument, not index state: a concurrent
-                                                    // caller's launch on the same handle is never forced)
+                              int force_variant,  // >= 0: fnv_tune's launches (an argument, not index state: a concurrent
+                                                  // caller's launch on the same handle is never forced)
+                              bool ids_by_option) {  // node_ids = the "output_node_ids" option, read under the handle's mutex
   if (!ix) return fail(FNV_ERR_INVALID, "index is null");
   // Index.h:847-849
   if (num_initializations <= 0) return fail(FNV_ERR_INVALID, "num_initializations must be greater than 0.");
@@ -923,6 +979,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   if (!d_queries || !d_out_dist || !d_out_labels) return fail(FNV_ERR_INVALID, "null buffer");
   if (nq > 0x7FFFFFFFull) return fail(FNV_ERR_INVALID, "too many queries in one batch");
   std::lock_guard<std::mutex> lock(ix->mu);
+  if (ids_by_option) node_ids = ix->output_node_ids != 0;
   ON_DEVICE(ix->device);
   hipStream_t stream = (hipStream_t)hip_stream;
 
@@ -994,7 +1051,9 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
                                                                  (B <= 2 * WAVE && bpc_w >= (int)ix->occupancy_roomy))));
       // both candidates once more with the free table growth; an LDS home that costs residency AND table slots is not taken
       SearchParams fin_w = p, fin_wo = p;
-      fin_w.cand_slots = with.cand_slots;
+      // (p's own heap size, not `with`'s: configure_launch may already have trimmed that one by up to an eighth to fit an LDS
+      //  granule, and the trim must be applied once, to the final layout)
+      fin_w.cand_slots = p.cand_slots;
       fin_wo.cand_slots = 0u;
       uint32_t flds_w = 0, flds_wo = 0;
       int fbpc_w = 0, fbpc_wo = 0;
@@ -1040,6 +1099,20 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     variant = variant_allowed(pinned, multi_round, true, shadows_on, true) ? pinned : 1;
     sorted = variant != 0;
     if (variant >= 2) tail_pct = kTailPct[variant];
+  } else if (sorted && ix->sorted_beam == 2 && ix->is_lane) {
+    // a hidden lane runs what its owner has measured (copied by sync_lane) and never explores or samples: a production
+    // caller that happens to land on a lane must not pay for 3 x variants exploratory launches per lane
+    if (nq >= 2048) {
+      if (auto it = ix->tuner.find(2 * B + (multi_round ? 1 : 0)); it != ix->tuner.end()) {
+        const fnv_index_s::Tuner& t = it->second;
+        int best = -1;
+        for (int v = 0; v < kNumVariants; v++)
+          if (variant_allowed(v, multi_round, try_tail, shadows_on) && t.samples[v] > 0 && (best < 0 || t.best[v] < t.best[best])) best = v;
+        if (best >= 0) variant = best;
+      }
+      sorted = variant != 0;
+      if (variant >= 2) tail_pct = kTailPct[variant];
+    }
   } else if (sorted && ix->sorted_beam == 2) {
     if (ix->sample_kernel >= 0 && ix->launched && hipEventQuery(ix->ev1) == hipSuccess) {
       float ms = 0.f;
@@ -1048,6 +1121,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
         const float per_q = ms / (float)ix->sample_nq;
         if (t.samples[ix->sample_kernel] == 0 || per_q < t.best[ix->sample_kernel]) t.best[ix->sample_kernel] = per_q;
         t.samples[ix->sample_kernel]++;
+        ix->tune_epoch++;  // (lanes re-copy the measurements)
       }
       ix->sample_kernel = -1;
     }
@@ -1085,10 +1159,19 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   const uint32_t max_slots = std::max<uint32_t>(nslots, (uint32_t)std::min<uint64_t>(nq, (uint64_t)std::max(plan.bpc, plan.sbpc) * (uint64_t)ix->num_cus));
 
   // ---- workspace (grown on demand; sized for whichever kernel keeps more slots resident) -------------------------
-  int rc = grow((void**)&ix->d_bitmap, &ix->bitmap_bytes, (size_t)max_slots * plan.heaps.bitmap_words * 4, true);
-  if (!rc) rc = grow((void**)&ix->d_ovf, &ix->ovf_bytes, (size_t)max_slots * plan.heaps.ovf_cap * 4);
-  if (!rc) rc = grow((void**)&ix->d_spill, &ix->spill_bytes, (size_t)max_slots * plan.heaps.spill_entries * 8);
-  if (!rc && (shadow || tail_shadows)) rc = grow((void**)&ix->d_done, &ix->done_bytes, (size_t)nq * 4);
+  int rc = FNV_OK;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    rc = grow((void**)&ix->d_bitmap, &ix->bitmap_bytes, (size_t)max_slots * plan.heaps.bitmap_words * 4, true);
+    if (!rc) rc = grow((void**)&ix->d_ovf, &ix->ovf_bytes, (size_t)max_slots * plan.heaps.ovf_cap * 4);
+    if (!rc) rc = grow((void**)&ix->d_spill, &ix->spill_bytes, (size_t)max_slots * plan.heaps.spill_entries * 8);
+    if (!rc && (shadow || tail_shadows)) rc = grow((void**)&ix->d_done, &ix->done_bytes, (size_t)nq * 4);
+    ix->ws_bytes = ix->bitmap_bytes + ix->ovf_bytes + ix->spill_bytes;
+    // out of memory on the handle itself: the hidden lanes' idle workspaces go first, then once more (not from inside
+    // fnv_tune, which holds the lanes)
+    if (rc != FNV_ERR_NO_DEVICE || attempt || ix->is_lane || ix->parent || force_variant >= 0) break;
+    (void)hipGetLastError();
+    if (release_idle_lanes(ix, nullptr) == 0) break;
+  }
   if (rc) return rc;
 
   SearchParams p = sorted ? plan.sorted : plan.heaps;
@@ -1159,6 +1242,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   ix->sample_nq = nq;
   ix->last_variant = sorted ? std::max(variant, 1) : 0;
   ix->last_exploratory = exploratory;
+  if (exploratory) ix->explored_launches++;
   ix->last_shadow = shadow;
   ix->last_stream = stream;
   ix->launched = true;
@@ -1220,11 +1304,19 @@ static int search_host_enqueue(fnv_index_t ix, const void* queries, uint64_t nq,
     // device-to-host copies each synchronise with the runtime's staging
     const size_t res_need = ((obytes + 63) & ~(size_t)63) + 64;
     if (!pinned && res_need <= (256u << 20) && res_need > ix->h_res_bytes) {
-      if (ix->h_res) HIP_TRY(hipHostFree(ix->h_res));
+      // best effort: pinned memory is commonly capped (ulimit -l, containers) -- without the slab the five pageable
+      // copies below still work
+      void* old = ix->h_res;
       ix->h_res = nullptr;
       ix->h_res_bytes = 0;
-      HIP_TRY(hipHostMalloc(&ix->h_res, res_need + res_need / 4, hipHostMallocDefault));
-      ix->h_res_bytes = res_need + res_need / 4;
+      if (old) (void)hipHostFree(old);
+      void* slab = nullptr;
+      if (hipHostMalloc(&slab, res_need + res_need / 4, hipHostMallocDefault) == hipSuccess && slab) {
+        ix->h_res = slab;
+        ix->h_res_bytes = res_need + res_need / 4;
+      } else {
+        (void)hipGetLastError();
+      }
     }
   }
   const bool pinned_results = !pinned && ix->h_res && ((obytes + 63) & ~(size_t)63) + 64 <= ix->h_res_bytes;
@@ -1309,12 +1401,13 @@ static int check_search_args(fnv_index_t ix, const void* queries, uint64_t nq, i
 // Hidden lane `which` (1 ... kMaxLanes - 1) of a handle (fnv_index_s::lanes): created on first contention.
 static fnv_index_s* hidden_lane(fnv_index_t ix, int which) {
   std::lock_guard<std::mutex> lock(ix->lane_mu);
-  if (!ix->lanes[which]) {
+  if (!ix->lanes[which].load()) {
     fnv_index_t v = nullptr;
     if (fnv_index_view(ix, &v) != FNV_OK) return nullptr;
+    v->is_lane = true;
     ix->lanes[which] = v;
   }
-  return ix->lanes[which];
+  return ix->lanes[which].load();
 }
 // The lane answers exactly like its owner: same options, same measured layouts and kernel choice (copied when they changed).
 static void sync_lane(fnv_index_t ix, fnv_index_s* lane) {
@@ -1347,19 +1440,25 @@ int fnv_search_batch(fnv_index_t ix, const void* queries, uint64_t nq, int K, in
   fnv_index_s* lane = ix;
   std::unique_lock<std::mutex> host_lock(ix->host_mu, std::try_to_lock);
   if (!host_lock.owns_lock() && !ix->parent) {
-    // large batches: two lanes, or four while a lane's launch workspace (per-slot visited bitmaps + candidate spill areas
-    // for a full grid) stays under 2 GB -- measured on 1M x 128 (r4_run18): 7.8 / 10.4 / 11.2 / 11.5 M queries/s from
-    // 1 / 2 / 3 / 4 caller threads with four lanes, 10.4 M from two on; at 10M and 50M nodes a lane's bitmaps alone are
-    // 3.5 GB and 19 GB
-    const uint64_t lane_workspace = 16ull * (uint64_t)ix->num_cus * (ix->capacity / 8 + (uint64_t)ix->spill_entries * 8);
-    const int usable = nq <= fnv_index_s::kSmallLaneQueries ? fnv_index_s::kMaxLanes : lane_workspace <= (2ull << 30) ? 4 : 2;
-    for (int which = 1; which < usable && !host_lock.owns_lock(); which++) {
+    // A lane is taken only if the HBM its launch workspace needs fits the budget for all hidden lanes together (round 5;
+    // fnv_index_s: an eighth of the device's memory) -- measured on 1M x 128 (r4_run18): 7.8 / 10.4 / 11.2 / 11.5 M queries/s
+    // from 1 / 2 / 3 / 4 caller threads on four lanes; at 50M nodes one full-grid lane is 19 GB and the second does not fit.
+    const size_t need = launch_workspace_bytes(ix, nq);
+    for (int which = 1; which < fnv_index_s::kMaxLanes && !host_lock.owns_lock(); which++) {
       if (fnv_index_s* l = hidden_lane(ix, which)) {
         std::unique_lock<std::mutex> lock2(l->host_mu, std::try_to_lock);
-        if (lock2.owns_lock()) {
-          lane = l;
-          host_lock = std::move(lock2);
-        }
+        if (!lock2.owns_lock()) continue;
+        auto others = [&]() {
+          size_t sum = 0;
+          for (int o = 1; o < fnv_index_s::kMaxLanes; o++)
+            if (fnv_index_s* other = o != which ? ix->lanes[o].load() : nullptr) sum += other->ws_bytes.load();
+          return sum;
+        };
+        const size_t mine = std::max<size_t>(l->ws_bytes.load(), need);
+        if (others() + mine > ix->lane_budget_bytes) (void)release_idle_lanes(ix, l);  // idle lanes give their room back first
+        if (others() + mine > ix->lane_budget_bytes) continue;                          // does not fit: not this lane
+        lane = l;
+        host_lock = std::move(lock2);
       }
     }
   }
@@ -1379,9 +1478,15 @@ int fnv_search_batch(fnv_index_t ix, const void* queries, uint64_t nq, int K, in
   }
   if (rc) return rc;
   rc = search_host_finish(lane);
-  if (lane != ix) {  // what fnv_last_launch_info reports for the handle: the most recent call, whichever lane served it
-    ix->t_enqueue_ns = lane->t_enqueue_ns;
-    ix->t_complete_ns = lane->t_complete_ns;
+  if (lane != ix) {  // what fnv_last_launch_info / _geometry report for the handle: the most recent call, whichever lane
+    std::lock_guard<std::mutex> l1(ix->mu);  // served it -- the whole record, under the handle's mutex (same order as sync_lane)
+    std::lock_guard<std::mutex> l2(lane->mu);
+    ix->t_enqueue_ns = lane->t_enqueue_ns.load();
+    ix->t_complete_ns = lane->t_complete_ns.load();
+    ix->last_variant = lane->last_variant;
+    ix->last_exploratory = lane->last_exploratory;
+    ix->last_shadow = lane->last_shadow;
+    for (int i = 0; i < 8; i++) ix->geom[i] = lane->geom[i];
   }
   return rc;
 }
@@ -1538,8 +1643,8 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
   //  that wants one waits on lane_mu, holding nothing)
   std::lock_guard<std::mutex> no_new_lanes(ix->lane_mu);
   std::vector<std::unique_lock<std::mutex>> lane_locks;
-  for (fnv_index_s* l : ix->lanes)
-    if (l) lane_locks.emplace_back(l->host_mu);
+  for (std::atomic<fnv_index_s*>& slot : ix->lanes)
+    if (fnv_index_s* l = slot.load()) lane_locks.emplace_back(l->host_mu);
   ON_DEVICE(ix->device);
   const size_t qbytes = (size_t)nq * ix->dim * dtype_size(ix->dtype);
   const size_t o_lab = (size_t)nq * K * 4, obytes = 2 * o_lab;
@@ -1559,7 +1664,7 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
   uint8_t* o = (uint8_t*)ix->d_out;
   auto launch = [&](int variant, uint64_t rotate = 0) -> int {
     return search_device_impl(ix, dq2 + (rotate % nq) * qrow_bytes, nq, K, ef_search, num_initializations, (float*)o,
-                              (int32_t*)(o + o_lab), nullptr, nullptr, nullptr, ix->stream, ix->output_node_ids != 0, variant);
+                              (int32_t*)(o + o_lab), nullptr, nullptr, nullptr, ix->stream, false, variant, /*ids_by_option=*/true);
   };
   // what kind of launch is this?  (one probing launch of the merged-beam kernel tells: plan, round size)
   const int B = std::max(ef_search, K);
@@ -1569,6 +1674,7 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
     ix->tuner.erase(2 * B);
     ix->tuner.erase(2 * B + 1);
     ix->plan.valid = false;
+    ix->tune_epoch++;  // (whatever follows -- including the early return below -- lanes drop their copy of the old choice)
   }
   int rc = launch(1);
   if (rc) return rc;
@@ -1688,6 +1794,7 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
     if (best_layout == 0) ix->layouts.erase(B);
     else ix->layouts[B] = cands[best_layout];
     ix->plan.valid = false;
+    ix->tune_epoch++;
   }
   rc = launch(1);  // re-plan with the chosen layout
   if (rc) return rc;
@@ -1777,8 +1884,8 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
   //  that wants one waits on lane_mu, holding nothing)
   std::lock_guard<std::mutex> no_new_lanes(ix->lane_mu);
   std::vector<std::unique_lock<std::mutex>> lane_locks;
-  for (fnv_index_s* l : ix->lanes)
-    if (l) lane_locks.emplace_back(l->host_mu);
+  for (std::atomic<fnv_index_s*>& slot : ix->lanes)
+    if (fnv_index_s* l = slot.load()) lane_locks.emplace_back(l->host_mu);
   ON_DEVICE(ix->device);
   const int W = ef_construction;
   const uint32_t keep = std::max<uint32_t>(ix->M / 2, 1);  // Index.h:373
@@ -1953,8 +2060,19 @@ int fnv_last_replayed_queries(fnv_index_t ix, uint64_t out[5]) {
   return FNV_OK;
 }
 
+int fnv_lane_info(fnv_index_t ix, uint64_t info[16]) {
+  if (!ix || !info) return fail(FNV_ERR_INVALID, "null argument");
+  for (int i = 0; i < fnv_index_s::kMaxLanes; i++) {
+    const fnv_index_s* l = i == 0 ? ix : ix->lanes[i].load();
+    info[2 * i] = l ? (uint64_t)l->ws_bytes.load() : 0;
+    info[2 * i + 1] = l ? l->explored_launches.load() : 0;
+  }
+  return FNV_OK;
+}
+
 int fnv_last_launch_geometry(fnv_index_t ix, uint64_t geom[8]) {
   if (!ix || !geom) return fail(FNV_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lock(ix->mu);
   for (int i = 0; i < 8; i++) geom[i] = ix->geom[i];
   return FNV_OK;
 }

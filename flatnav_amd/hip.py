@@ -26,7 +26,7 @@ C_ABI_SYMBOLS = [
     "fnv_index_set_live_nodes", "fnv_index_write_nodes", "fnv_index_write_links", "fnv_index_insert_batch",
     "fnv_index_read_links", "fnv_last_replayed_queries", "fnv_replicate", "fnv_replica_refresh",
     "fnv_search_batch_multi", "fnv_index_view", "fnv_tune", "fnv_last_launch_info", "fnv_gather_ceiling",
-    "fnv_index_adopt",
+    "fnv_index_adopt", "fnv_lane_info",
 ]
 
 _lib = None
@@ -83,6 +83,7 @@ def lib() -> C.CDLL:
     L.fnv_tune.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int]
     L.fnv_last_launch_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.fnv_gather_ceiling.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+    L.fnv_lane_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -328,3 +329,19 @@ class DeviceIndex:
         out["kernel"] = ["two_heaps", "merged_beam_registers", "merged_beam_lds"][int(g[6])]
         out["tail_exact"] = int(g[7])
         return out
+
+
+def _lane_info(dev) -> list:
+    r = (C.c_uint64 * 16)()
+    check(lib().fnv_lane_info(dev._h, r))
+    return [int(x) for x in r]
+
+
+def lane_workspaces(dev) -> list:
+    """Bytes of launch workspace (HBM) held by the handle [0] and by each of its hidden lanes [1..7] (fnv_lane_info)."""
+    return _lane_info(dev)[0::2]
+
+
+def lane_exploratory_launches(dev) -> list:
+    """Exploratory launches of the adaptive kernel choice on the handle [0] and on each hidden lane [1..7] (always 0 there)."""
+    return _lane_info(dev)[1::2]

@@ -46,7 +46,9 @@ def broadcast_buffers(tensors: List["torch.Tensor"], src: int = 0, group=None, p
 
     stats = []
     for t in tensors:
-        flat = t.reshape(-1)
+        # (view, not reshape: on a non-contiguous tensor reshape would copy, and the non-source ranks would receive into a
+        #  temporary while the caller's buffer stays unfilled -- view raises instead)
+        flat = t.view(-1)
         per = max(1, piece_bytes // max(1, flat.element_size()))
         pieces = 0
         if sync:

@@ -209,10 +209,20 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
 int fnv_set_option(fnv_index_t index, const char* name, int64_t value);
 
 /* Thread safety: fnv_search_batch may be called concurrently on one index: the first caller uses the handle's own
- * stream / workspace / staging, a second concurrent caller runs on a hidden second lane (a view of the handle, created
- * on first contention: its copies and its launch overlap the first caller's -- round 4); large batches use up to four
- * lanes while a lane's launch workspace stays under 2 GB (1M-node indexes), else two; batches of at most 1024 queries
- * up to eight (single queries from many threads are in flight together); further callers wait;
+ * stream / workspace / staging, a concurrent caller runs on a hidden lane (a view of the handle, created on first
+ * contention: its copies and its launch overlap the first caller's -- round 4), up to seven of them; further callers
+ * wait.  HBM: every lane owns a launch workspace like the handle's -- per resident query slot a visited bitmap of
+ * capacity / 8 bytes, a 128 KB candidate spill area and (indexes beyond 4M nodes) a 64 KB overflow list; a full grid is
+ * 0.6 GB at 1M nodes, 3.5 GB at 10M, 19 GB at 50M, a 1024-query batch at 50M nodes 6.4 GB.  A lane is only used while
+ * the workspaces of all hidden lanes together stay within an eighth of the device's memory (FLATNAV_LANE_BUDGET_MB
+ * overrides; 0 = no lanes): idle lanes give their workspace back when another lane or the handle itself needs the room,
+ * a caller whose batch fits no lane waits for the handle (round 5).  Lanes run the kernel variant and LDS layout the
+ * handle has measured and never take exploratory samples themselves.
+ * What may race with a search: fnv_set_option -- it takes the handle's mutex, every launch sees the options either before
+ * or after the change (the reference's only runtime knob, setNumThreads, Index.h:492-502, is not meant to be called during
+ * a search either); fnv_last_launch_info / fnv_last_launch_geometry -- consistent records of ONE launch, the most recent
+ * to complete on any lane; fnv_tune and fnv_index_insert_batch keep every lane out while they run.  NOT allowed while
+ * searches are in flight: fnv_index_free, fnv_replica_refresh towards the handle.
  * fnv_search_batch_device shares one per-index workspace, so at most one such launch may be in flight per index
  * (launches on the same stream are naturally ordered).  Different indexes are independent.
  *
@@ -296,6 +306,12 @@ int fnv_last_launch_geometry(fnv_index_t index, uint64_t geom[8]);
 int fnv_tune(fnv_index_t index, const void* queries, uint64_t nq, int queries_on_device, int K, int ef_search,
              int num_initializations);
 int fnv_last_launch_info(fnv_index_t index, uint64_t info[4]);
+
+/* What the handle (i = 0) and its hidden lanes (i = 1 ... 7; see fnv_search_batch) hold and did: info[2 i] = bytes of launch
+ * workspace in HBM (visited bitmaps, overflow lists, candidate spill areas), info[2 i + 1] = launches that were exploratory
+ * samples of the adaptive kernel choice (always 0 on a lane).  No reference counterpart (the reference's per-search state is
+ * a VisitedSet from a pool, VisitedSetPool.h:16-50, and it has one search routine). */
+int fnv_lane_info(fnv_index_t index, uint64_t info[16]);
 
 /* Measurement aid (bench.py's roofline.gather_ceiling): GB/s of row bytes that a pure gather of random rows of this
  * index's vector table reaches with the search kernel's own load pattern for this row width (lane groups, loads in

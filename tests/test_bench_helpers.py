@@ -38,6 +38,107 @@ def test_compact_keeps_the_contract_fields_and_rounds_the_rest():
     json.dumps(out)
 
 
+def _full_entry(name, cpu=True, world=1):
+    """An entry of the shape run_config() returns, with strings as long as the real ones."""
+    e = {"metric": "qps_at_recall10_ge_0.95", "value": 9634766.123456789, "unit": "queries/s", "n_gpus": world, "steps": 20,
+         "warmup": 5, "ms_per_step": 1.0378912345, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+         "dtype": "f32", "data": "synthetic",
+         "config": {"workload": "%s [%s]: 50000000 x 128 float32 inner product, M=32, ef_construction=100, ef_search=1600, K=10, "
+                                "10000 batched queries per GPU per step (a different batch every step), index in HBM" % (name, "t" * 90),
+                    "recall_at_10": 0.9511, "recall_queries": 10000, "ef_search": 1600,
+                    "recall_all_timed_batches": {"min": 0.9507, "mean": 0.9521, "batches": 20, "queries_per_batch": 10000},
+                    "ef_selection": "x" * 600, "data_note": "y" * 200, "index_build": "z" * 120,
+                    "parallelism": "index replicated x%d, queries sharded" % world,
+                    "multi_gpu": None if world == 1 else {
+                        "per_rank_queries_per_s": [1.2e6 + i for i in range(world)], "per_rank_seconds": [0.1] * world,
+                        "index_broadcast": [{"buffer": b, "bytes": 3.2e10, "pieces": 16, "seconds": 0.3, "GBps": 101.123456}
+                                            for b in ("vectors", "links", "labels")],
+                        "peer_access": [[1] * world] * world, "note": "n" * 200},
+                    "launch": {"grid_blocks": 4096, "block_threads": 64, "lds_bytes": 10144, "blocks_per_cu": 16, "visited_slots": 2048,
+                               "cand_slots": 296, "kernel": "merged_beam_registers", "tail_exact": 4096, "resident_per_cu": 16},
+                    "kernel_variant": 5, "kernel_choice": "k" * 200, "exploratory_timed_launches": 0,
+                    "queries_replayed_by_exact_kernel": 141, "host_buffer_qps_pcie_inclusive": 8234567,
+                    "host_buffer_qps_two_caller_threads": 9400000, "host_buffer_qps_four_caller_threads": 11500000,
+                    "index_bytes_in_hbm": 644000000, "index_fraction_in_infinity_cache": 0.417, "measured_in_this_run": "m" * 200},
+         "roofline": {"bound": "hbm", "kernel": "fnv_dev::beam_search_merged_kernel", "achieved": 6228.123456789, "peak": 8000.0,
+                      "unit": "GB/s", "frac": 0.7785154320986, "gather_ceiling": 7113.987654321, "frac_of_gather_ceiling": 0.87548,
+                      "gather_ceiling_note": "g" * 300, "traffic": None,
+                      "traffic_recorded": {"hbm_bytes_per_launch_corrected": 5838123456.0, "source": "profiles/r4_pmc_hbm_traffic.json (...)"},
+                      "algorithmic_bytes_per_launch": 6415712345.5, "row_bytes": 512, "row_stride_bytes": 512,
+                      "line_bytes_per_launch": 6415712345.5, "achieved_line_GBps": 6228.1, "avg_kernel_ms": 1.0301234,
+                      "trace_position": {"timed": 20, "regions": 3, "after": 91}},
+         "timed_regions": {"n": 3, "min": 9534766.1, "median": 9634766.123456789, "max": 9734766.9, "kernel_ms": [1.03, 1.031, 1.029], "note": "n" * 90},
+         "secondary": [], "sustained": {"value": 9.5e6}, "pipelined": {"value": 12034567.8, "note": "p" * 150}}
+    if cpu:
+        e["cpu_baseline"] = {"value": 143630.123, "unit": "queries/s", "cores": 16, "kind": "port", "sample": "s" * 420,
+                             "sample_short": "9 x first 10000 queries of batch 0, 16 threads (1 thread: 10912 q/s); GPU ids == CPU ids on "
+                                             "100.00% of them; reference's AVX-512 distance kernel"}
+    return e
+
+
+def _record(names, world=1):
+    out = _full_entry("c2", cpu=world == 1, world=world)
+    out["secondary"] = [{"ef_search": 100, "value": 5.4e6, "unit": "queries/s", "recall_at_10": 0.9901, "roofline_frac": 0.7312345}]
+    for n in names:
+        e = _full_entry(n, cpu=world == 1, world=world)
+        e["ef_lines"] = e.pop("secondary")
+        out[n] = e
+        out["secondary"].append({"config": n, "value": e["value"], "unit": "queries/s", "ef_search": 1600, "recall_at_10": 0.9511,
+                                 "roofline_frac": 0.61, "full_entry": "top-level key"})
+    out["bench_wall_seconds"] = 663.1
+    return out
+
+
+def test_contract_line_of_a_seven_configuration_run_stays_under_4_kb():
+    # BENCH_r04.json: "parsed": null -- the one stdout line had grown to 25 KB.  Whatever the run holds, the line that goes to
+    # stdout is at most 4 KB, parses, and carries roofline + cpu_baseline + one row per further configuration.
+    names = bench.SECONDARY_DEFAULT[1].split(",")
+    assert len(names) == 6
+    out = _record(names)
+    out["c5"] = {"skipped": "failed: MemoryError: " + "x" * 300}
+    out["secondary"][-2] = {"config": "c5", "skipped": True, "error": "MemoryError"}
+    text = bench.contract_line(out, names, "c2", "bench_out/bench_full.json")
+    assert len(text.encode()) < bench.CONTRACT_LINE_MAX and "\n" not in text
+    d = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "value_pcie_inclusive", "secondary"):
+        assert k in d, k
+    assert d["value"] == out["value"] and d["ms_per_step"] == out["ms_per_step"]  # the contract's own numbers keep every digit
+    assert d["config"]["workload"].startswith("c2 ") and d["config"]["ef_search"] == 1600 and d["config"]["recall_min_over_timed_batches"] == 0.9507
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 and r["traffic"] is None
+    assert abs(r["traffic_over_algorithmic"] - 0.91) < 0.005 and r["avg_kernel_ms"] > 0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 16 and "100.00%" in d["cpu_baseline"]["sample"]
+    assert d["value_pcie_inclusive"] == 8234567 and d["timed_regions"]["n"] == 3
+    rows = {row["config"]: row for row in d["secondary"] if row["config"] != "c2"}
+    assert set(rows) == set(names) and "skipped" in rows["c5"] and rows["c4"]["frac"] == 0.779 and rows["c4"]["cpu"] > 0
+    assert all(len(json.dumps(row)) <= 220 for row in d["secondary"])
+    # the 8-GPU shape: per-rank lists and the broadcast report stay in the file, three numbers in the line
+    text8 = bench.contract_line(_record(["c5"], world=8), ["c5"], "c2", None)
+    d8 = json.loads(text8)
+    assert len(text8.encode()) < bench.CONTRACT_LINE_MAX and d8["n_gpus"] == 8 and "cpu_baseline" not in d8
+    assert set(d8["multi_gpu"]) == {"slowest_rank_qps", "fastest_rank_qps", "index_broadcast_GBps_min"}
+
+
+def test_contract_line_sheds_optional_parts_before_it_outgrows_the_limit():
+    names = bench.SECONDARY_DEFAULT[1].split(",") * 6  # 36 further configurations: more rows than 4 KB hold
+    out = _record(list(dict.fromkeys(names)))
+    for i in range(30):
+        out["secondary"].append(dict(out["secondary"][1], config="c4"))
+    text = bench.contract_line(out, names, "c2", "bench_out/bench_full.json")
+    d = json.loads(text)
+    assert len(text.encode()) <= bench.CONTRACT_LINE_MAX
+    assert d["value"] == out["value"] and d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0 and d["secondary"]
+
+
+def test_full_record_goes_to_a_file(tmp_path, capsys):
+    path = str(tmp_path / "sub" / "bench_full.json")
+    assert bench.write_full_record(bench.compact(_record(["c4"])), path) == path
+    assert json.load(open(path))["c4"]["roofline"]["frac"] == 0.778515
+    assert "[bench] full record: {" in capsys.readouterr().err
+    assert bench.write_full_record({"a": 1}, "/proc/nonexistent/x.json") is None  # best effort: the line still goes out
+
+
 def test_configuration_table_is_consistent():
     assert set(bench.SECONDARY_DEFAULT[1].split(",")) <= set(bench.CONFIGS) and "c2" not in bench.SECONDARY_DEFAULT[1].split(",")
     for name, cfg in bench.CONFIGS.items():

@@ -14,72 +14,87 @@ SMALL = ["--index-size", "60000", "--nq", "2000", "--steps", "2", "--warmup", "1
 
 
 def _last_json(out):
-    lines = [l for l in out.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out[-3000:]
+    """stdout carries exactly ONE line, the contract line, at most 4 KB (BENCH_r04.json: a 25 KB line was not parsed)."""
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out[-3000:]
+    assert len(lines[0].encode()) <= 4096, len(lines[0])
     return json.loads(lines[0])
 
 
-def test_single_gpu_line_has_the_contract_fields():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, capture_output=True, text=True,
-                         timeout=900, cwd=ROOT)
+def _run(cmd, tmp_path, env=None, timeout=900):
+    """-> (contract line, full record)"""
+    full = str(tmp_path / "bench_full.json")
+    out = subprocess.run(cmd + ["--full-record", full], capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     d = _last_json(out.stdout)
+    assert d["full_record"] == full
+    return d, json.load(open(full))
+
+
+def test_single_gpu_line_has_the_contract_fields(tmp_path):
+    d, full = _run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, tmp_path)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "value_pcie_inclusive", "timed_regions"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dtype"] == "f32"
-    assert d["config"]["recall_at_10"] >= 0.95 and "workload" in d["config"]
+    assert d["config"]["recall_at_10"] >= 0.95 and "workload" in d["config"] and d["config"]["recall_min_over_timed_batches"] >= 0.95
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5  # (floats below the top level carry six digits)
     assert r["gather_ceiling"] > r["achieved"] > 0 and 0 < r["frac_of_gather_ceiling"] < 1  # pure gather beats gather + search
-    assert r["algorithmic_bytes_per_launch"] <= r["line_bytes_per_launch"]
+    assert r["algorithmic_bytes_per_launch"] > 0 and r["avg_kernel_ms"] > 0
+    assert full["roofline"]["algorithmic_bytes_per_launch"] <= full["roofline"]["line_bytes_per_launch"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "100.00%" in c["sample"]  # GPU ids == CPU ids
-    assert "timed launches that were exploratory samples of the adaptive choice: 0" in d["config"]["kernel_choice"]
+    assert d["config"]["exploratory_timed_launches"] == 0
+    # value = the median of three timed regions of --steps launches each; the same number in line and file
+    t = d["timed_regions"]
+    assert t["n"] == 3 and t["min"] <= t["median"] <= t["max"] and abs(t["median"] - d["value"]) < 1e-4 * d["value"]
+    assert full["value"] == d["value"] and full["ms_per_step"] == d["ms_per_step"] and d["value_pcie_inclusive"] > 0
 
 
-def test_default_line_carries_the_other_configurations():
-    # the default invocation runs the further BASELINE configurations after the main one and reports each as a full
-    # entry under its own top-level key (here at test sizes: --secondary-index-size)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL +
-                         ["--secondary-configs", "c4,c5-lowrank", "--secondary-index-size", "50000"],
-                         capture_output=True, text=True, timeout=1200, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-3000:]
-    d = _last_json(out.stdout)
+def test_default_run_carries_the_other_configurations(tmp_path):
+    # the default invocation runs the further BASELINE configurations after the main one: each is a full entry under its
+    # own key of the full record and ONE short row of the contract line (here at test sizes: --secondary-index-size)
+    d, full = _run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL +
+                   ["--secondary-configs", "c2-uint8,c4,c5-lowrank", "--secondary-index-size", "50000"], tmp_path, timeout=1500)
     assert d["config"]["workload"].startswith("c2 ")
-    for name in ("c4", "c5-lowrank"):
-        e = d[name]
+    rows = {x["config"]: x for x in d["secondary"] if x["config"] != "c2"}
+    for name in ("c2-uint8", "c4", "c5-lowrank"):
+        e = full[name]
         assert e["config"]["workload"].startswith(name + " ") and e["value"] > 0 and e["config"]["recall_at_10"] >= 0.95
         assert e["roofline"]["algorithmic_bytes_per_launch"] > 0 and 0 < e["roofline"]["frac"] < 1
         assert e["cpu_baseline"]["value"] > 0 and "GPU ids == CPU ids" in e["cpu_baseline"]["sample"]
-        assert any(x.get("config") == name and x["value"] == e["value"] for x in d["secondary"])
-    assert len(d["c4"]["ef_lines"]) == 4  # the fixed-ef sweep of c4
+        row = rows[name]
+        assert abs(row["value"] - e["value"]) < 1e-3 * e["value"] and row["ef"] == e["config"]["ef_search"] and row["cpu"] > 0
+        assert row["min"] <= row["value"] * 1.0001 and row["value"] <= row["max"] * 1.0001 and 0 < row["frac"] < 1
+    assert len(full["c4"]["ef_lines"]) == 4  # the fixed-ef sweep of c4
+    assert len(full["summary"]) == 4
 
 
-def test_two_ranks_share_one_gpu_over_gloo():
+def test_two_ranks_share_one_gpu_over_gloo(tmp_path):
     env = dict(os.environ, BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
-    d = _last_json(out.stdout)
+    d, full = _run(cmd, tmp_path, env=env)
     assert d["n_gpus"] == 2 and "cpu_baseline" not in d
     assert d["config"]["parallelism"].startswith("index replicated x2")
     assert d["config"]["recall_at_10"] >= 0.95 and d["value"] > 0
+    # three numbers in the line; per-rank rates, the broadcast report and the peer matrix in the file
+    assert d["multi_gpu"]["slowest_rank_qps"] <= d["multi_gpu"]["fastest_rank_qps"] and d["multi_gpu"]["index_broadcast_GBps_min"] > 0
+    mg = full["config"]["multi_gpu"]
+    assert len(mg["per_rank_queries_per_s"]) == 2 and len(mg["index_broadcast"]) == 3 and len(mg["peer_access"]) >= 1
 
 
-def test_two_ranks_also_run_the_multi_gpu_configuration():
+def test_two_ranks_also_run_the_multi_gpu_configuration(tmp_path):
     # with N > 1 GPUs the default line carries c5 (the configuration worded for 8 GPUs) after the main one: every rank
     # takes part in its broadcast, ef agreement and timing barriers (here at a test size, two ranks on the one GPU)
     env = dict(os.environ, BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL + [
                "--secondary-configs", "c5", "--secondary-index-size", "40000"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
-    d = _last_json(out.stdout)
+    d, full = _run(cmd, tmp_path, env=env)
     assert d["n_gpus"] == 2 and d["config"]["workload"].startswith("c2 ")
-    e = d["c5"]
+    e = full["c5"]
     assert e["n_gpus"] == 2 and e["config"]["workload"].startswith("c5 ") and e["value"] > 0
     assert e["config"]["parallelism"].startswith("index replicated x2") and "cpu_baseline" not in e
     assert any(x.get("config") == "c5" for x in d["secondary"])
@@ -104,7 +119,7 @@ def test_benchmark_harness_writes_the_reference_metrics(tmp_path):
     assert exps[1]["recall"] >= exps[0]["recall"]
 
 
-def test_bench_spawns_its_own_ranks_and_runs_other_configs():
+def test_bench_spawns_its_own_ranks_and_runs_other_configs(tmp_path):
     # `python bench.py --gpus 2` without a torch.distributed environment launches the two ranks itself; c4 (100-d
     # inner product) exercises a configuration other than the default, at a reduced size
     env = dict(os.environ, BENCH_SHARE_GPU="1")
@@ -112,12 +127,10 @@ def test_bench_spawns_its_own_ranks_and_runs_other_configs():
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c4", "--index-size", "50000",
            "--nq", "1000", "--steps", "2", "--warmup", "1", "--no-secondary"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
-    d = _last_json(out.stdout)
+    d, full = _run(cmd, tmp_path, env=env)
     assert d["n_gpus"] == 2 and d["config"]["workload"].startswith("c4 ") and d["value"] > 0
     assert d["roofline"]["frac_of_gather_ceiling"] > 0 and d["roofline"]["frac"] > 0  # (a 25 MB table gathers from L2: ceiling > HBM peak)
-    assert d["roofline"]["row_bytes"] == 400 and d["roofline"]["row_stride_bytes"] == 512  # 100-d rows on whole lines
+    assert full["roofline"]["row_bytes"] == 400 and full["roofline"]["row_stride_bytes"] == 512  # 100-d rows on whole lines
 
 
 @pytest.mark.parametrize("metric", ["l2", "angular"])

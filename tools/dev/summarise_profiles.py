@@ -10,7 +10,7 @@ import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 O = os.path.join(ROOT, "gpurun_out", "profile_set")
 P = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
 CONFIGS = ["c2", "c2-uint8", "c4", "c3-lowrank", "c3", "c5", "c5-lowrank"]
 
 
@@ -42,7 +42,8 @@ def timed_launches(c, steps):
     # device builder's and fnv_tune's other variants launch other grids); rocprofv3 counts work-items
     blocks = j["config"]["launch"]["grid_blocks"]
     full = [r for r in rows if int(r["Grid_Size_X"]) in (blocks, blocks * 64)]
-    after, steps = j["roofline"]["trace_position"]["after"], j["roofline"]["trace_position"]["timed"]  # counted by bench.py itself
+    pos = j["roofline"]["trace_position"]  # counted by bench.py itself; the timed regions are back to back
+    after, steps = pos["after"], pos["timed"] * pos.get("regions", 1)
     sel = full[-(after + steps):-after]
     dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in sel]
     r0 = sel[0]
@@ -60,7 +61,7 @@ def counters(d, steps=3):
     after = None
     try:
         pos = json.load(open(os.path.join(O, d + ".json")))["roofline"]["trace_position"]
-        after, steps = pos["after"], pos["timed"]
+        after, steps = pos["after"], pos["timed"] * pos.get("regions", 1)
     except (OSError, KeyError, ValueError):
         pass
     rows = [r for r in csv.DictReader(open(f)) if "beam_search" in r["Kernel_Name"]]
@@ -72,7 +73,7 @@ def counters(d, steps=3):
     ids = sorted({int(r["Dispatch_Id"]) for r in rows})
     if after is None:  # (a pass whose bench line was not kept: same command as the FETCH pass of the same configuration)
         pos = json.load(open(os.path.join(O, "fetch_" + d.split("_", 1)[1] + ".json")))["roofline"]["trace_position"]
-        after, steps = pos["after"], pos["timed"]
+        after, steps = pos["after"], pos["timed"] * pos.get("regions", 1)
     ids = ids[-(after + steps):-after]
     rows = [r for r in rows if int(r["Dispatch_Id"]) in ids]
     acc = collections.defaultdict(list)
@@ -85,7 +86,7 @@ def counters(d, steps=3):
 
 ONE = None
 if len(sys.argv) > 2 and sys.argv[1] == "--one":
-    ONE, tag = sys.argv[2], "r4"
+    ONE, tag = sys.argv[2], "r5"
     CONFIGS = [ONE]
 SUM = os.path.join(O, "summary")
 os.makedirs(SUM, exist_ok=True)
@@ -127,7 +128,7 @@ for c in CONFIGS:
             "config": c.replace("-uint8", ""), "dtype": "uint8" if c.endswith("uint8") else "float32",
             "n": int(fj["config"]["index_bytes_in_hbm"] // (r["row_stride_bytes"] + 132)), "nq": 10000, "ef": fj["config"]["ef_search"], "kernel": meta,
             "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --config %s --ef %d "
-                       "--no-cpu-baseline --no-secondary --sustain-seconds 0 --warmup 3 --steps 3" % (c, fj["config"]["ef_search"]),
+                       "--no-cpu-baseline --no-secondary --sustain-seconds 0 --warmup 3 --regions 1 --steps 3" % (c, fj["config"]["ef_search"]),
             "FETCH_SIZE_KB_per_launch": F, "WRITE_SIZE_KB_per_launch": W,
             "correction": "MI355X_MICROARCH.md HBM section: hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024; on gfx950 FETCH_SIZE tallies each "
                           "128-B request of a 16 B/lane coalesced read as 64 B -> read side doubled",
@@ -145,7 +146,7 @@ if ONE:
     sys.exit(0)
 with open(os.path.join(P, "%s_kernel_trace_timed_regions.csv" % tag), "w") as fo:
     fo.write("# per configuration: the timed region's search launches of `rocprofv3 --kernel-trace --stats -- python3 bench.py --config <c> --ef <ef> "
-             "--no-cpu-baseline --no-secondary --sustain-seconds 0 --warmup 3 --steps <calls>` (positions from the end of the process's full-grid launches)\n")
+             "--no-cpu-baseline --no-secondary --sustain-seconds 0 --warmup 3 --regions 1 --steps <calls>` (positions from the end of the process's full-grid launches)\n")
     cols = ["config", "ef", "kernel", "calls", "avg_ns", "min_ns", "max_ns", "grid", "workgroup", "lds", "vgpr", "sgpr", "scratch", "bench_events_avg_ms",
             "algorithmic_bytes_per_launch"]
     fo.write(",".join(cols) + ",achieved_GBps,frac_of_8TBps\n")
