@@ -212,7 +212,7 @@ struct IndexOptions {
           cand_slots = 0, spill_entries = 16384, blocks_per_cu = 0, visited_wide = 0,
           entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0, sorted_beam = 2,
           sorted_beam_min = 1, sorted_cand_lds = 2, sorted_tail_exact_pct = -1, beam_registers = 1,
-          sorted_variant = -1, tune_layout = 1, shadow_exact = 1;
+          sorted_variant = -1, tune_layout = 1, shadow_exact = 1, tie_replay = 1, tie_log_entries = 0;
   int64_t overflow_list = -1;  // -1: automatic (a list in HBM only when the bitmap is larger than 512 KB)
 };
 
@@ -269,7 +269,8 @@ struct fnv_index_s : IndexOptions {
   // host-buffer searches: steady-clock time of launch / of completion (atomic: every lane's caller reports into the handle)
   std::atomic<uint64_t> t_enqueue_ns{0}, t_complete_ns{0};
   // workspace (grown on demand)
-  uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status, [3] queries a merged-beam launch searched exactly, [4..7] by reason
+  uint32_t* d_dispenser = nullptr;  // [0] dispenser, [1] status, [3] queries a merged-beam launch handed to the exact search, [4..7] by
+                                    // reason, [8] of them resumed from their log, [9] hops taken from logs, [10] hops of those queries
   unsigned long long* d_phase = nullptr;  // profiling builds only
   void* d_entry = nullptr;  // [nq] uint32 entry nodes | [nq] float entry distances (K0 output)
   size_t entry_bytes = 0;
@@ -287,6 +288,8 @@ struct fnv_index_s : IndexOptions {
   size_t spill_bytes = 0;
   uint32_t* d_done = nullptr;  // shadow mode: [nq] "answered" flags
   size_t done_bytes = 0;
+  unsigned long long* d_tielog = nullptr;  // merged-beam kernel: [nslots][log_entries] hand-over log (round 5)
+  size_t tielog_bytes = 0;
   // staging for the host-buffer entry point
   void* h_pin = nullptr;  // 1 MB of pinned host memory: staging of small host-buffer searches
   void* h_res = nullptr;  // pinned host memory for the result slab of larger host-buffer searches (grown on demand)
@@ -341,8 +344,8 @@ int index_common_init(fnv_index_s* ix) {
   HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&ix->ev0));
   HIP_TRY(hipEventCreate(&ix->ev1));
-  HIP_TRY(hipMalloc(&ix->d_dispenser, 8 * sizeof(uint32_t)));
-  HIP_TRY(hipMemset(ix->d_dispenser, 0, 8 * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&ix->d_dispenser, 16 * sizeof(uint32_t)));
+  HIP_TRY(hipMemset(ix->d_dispenser, 0, 16 * sizeof(uint32_t)));
 #ifdef FNV_PHASE_TIMING
   HIP_TRY(hipMalloc(&ix->d_phase, NPHASE * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(ix->d_phase, 0, NPHASE * sizeof(unsigned long long)));
@@ -611,7 +614,7 @@ int fnv_index_free(fnv_index_t ix) {
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
   if (ix->parent) ix->parent->n_views.fetch_sub(1);
   if (!ix->owns_buffers) ix->d_vectors = nullptr, ix->d_links = nullptr, ix->d_labels = nullptr;
-  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_bitmap, ix->d_ovf, ix->d_nodestage, ix->d_linkstage, ix->d_wirebuf, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase, ix->d_entry, ix->d_done};
+  void* bufs[] = {ix->d_vectors, ix->d_links, ix->d_labels, ix->d_dispenser, ix->d_bitmap, ix->d_ovf, ix->d_nodestage, ix->d_linkstage, ix->d_wirebuf, ix->d_spill, ix->d_q, ix->d_out, ix->d_phase, ix->d_entry, ix->d_done, ix->d_tielog};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (ix->h_pin) (void)hipHostFree(ix->h_pin);
@@ -714,6 +717,8 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   else if (n == "visited_tag_bits") ix->visited_tag_bits = value;
   else if (n == "tune_layout") ix->tune_layout = value;
   else if (n == "shadow_exact") ix->shadow_exact = value;
+  else if (n == "tie_replay") ix->tie_replay = value;
+  else if (n == "tie_log_entries") ix->tie_log_entries = value;
   else return fail(FNV_ERR_INVALID, "unknown option: " + n);
   // What fnv_tune measured (kernel variant, LDS layout) stays valid across options that change neither the launch plan
   // nor the kernel choice: Index.h::addBatchDevice flips output_node_ids around every device build, and a tune costs
@@ -941,9 +946,9 @@ static size_t release_idle_lanes(fnv_index_s* ix, const fnv_index_s* keep) {
     if (!idle.owns_lock()) continue;
     std::lock_guard<std::mutex> lk(l->mu);
     DeviceScope scope(l->device);
-    void** bufs[] = {(void**)&l->d_bitmap, (void**)&l->d_ovf, (void**)&l->d_spill};
-    size_t* sizes[] = {&l->bitmap_bytes, &l->ovf_bytes, &l->spill_bytes};
-    for (int i = 0; i < 3; i++) {
+    void** bufs[] = {(void**)&l->d_bitmap, (void**)&l->d_ovf, (void**)&l->d_spill, (void**)&l->d_tielog};
+    size_t* sizes[] = {&l->bitmap_bytes, &l->ovf_bytes, &l->spill_bytes, &l->tielog_bytes};
+    for (int i = 0; i < 4; i++) {
       if (*bufs[i]) (void)hipFree(*bufs[i]);
       *bufs[i] = nullptr;
       freed += *sizes[i];
@@ -962,7 +967,8 @@ static size_t launch_workspace_bytes(fnv_index_s* ix, uint64_t nq) {
   const uint64_t ovf_cap = ix->overflow_list >= 0 ? (uint64_t)ix->overflow_list : (bitmap_words * 4 > (512u << 10) ? 16384u : 0u);
   const int per_cu = ix->plan.valid ? std::max(ix->plan.bpc, ix->plan.sbpc) : 32;  // (no plan yet: the hardware's 32 waves per CU)
   const uint64_t slots = std::min<uint64_t>(2 * nq, (uint64_t)per_cu * (uint64_t)ix->num_cus);  // (small launches: a shadow per query)
-  return (size_t)(slots * (bitmap_words * 4 + ovf_cap * 4 + (uint64_t)ix->spill_entries * 8));
+  const uint64_t log_entries = ix->plan.valid ? ix->plan.sorted.log_entries : 16384u;
+  return (size_t)(slots * (bitmap_words * 4 + ovf_cap * 4 + (uint64_t)ix->spill_entries * 8 + log_entries * 8));
 }
 
 static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq, int K, int ef_search,
@@ -1009,6 +1015,12 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     p.bitmap_words = (uint32_t)(((ix->capacity + 31) / 32 + 3) / 4 * 4);  // whole 16-byte groups: wide clears
     p.ovf_cap = ix->overflow_list >= 0 ? (uint32_t)ix->overflow_list
                                        : ((uint64_t)p.bitmap_words * 4 > (512u << 10) ? 16384u : 0u);
+    // hand-over log (kernels.hpp): a query logs ~6 records per beam entry on the reference workloads (1M x 128 at ef=52: ~310;
+    // a hop is a header + the row's admissible neighbours); 24 per entry + 512, in [1024, 16384] records of 8 bytes per slot
+    // = 8-128 KB.  A log that overflows ends (the query is searched again from scratch if equal keys meet).
+    p.log_entries = !ix->tie_replay ? 0u
+                    : ix->tie_log_entries ? (uint32_t)std::max<int64_t>(WAVE + 2, ix->tie_log_entries)
+                                          : std::min<uint32_t>(16384u, std::max<uint32_t>(1024u, pow2_ceil(24ull * (uint64_t)p.B + 512)));
     const bool full = (p.nchunks % per_iter) == 0;  // rows are whole spans: the lean FULL kernels apply
     plan.cfg = cfg;
     plan.full = full;
@@ -1165,7 +1177,8 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     if (!rc) rc = grow((void**)&ix->d_ovf, &ix->ovf_bytes, (size_t)max_slots * plan.heaps.ovf_cap * 4);
     if (!rc) rc = grow((void**)&ix->d_spill, &ix->spill_bytes, (size_t)max_slots * plan.heaps.spill_entries * 8);
     if (!rc && (shadow || tail_shadows)) rc = grow((void**)&ix->d_done, &ix->done_bytes, (size_t)nq * 4);
-    ix->ws_bytes = ix->bitmap_bytes + ix->ovf_bytes + ix->spill_bytes;
+    if (!rc && sorted) rc = grow((void**)&ix->d_tielog, &ix->tielog_bytes, (size_t)max_slots * plan.sorted.log_entries * 8);
+    ix->ws_bytes = ix->bitmap_bytes + ix->ovf_bytes + ix->spill_bytes + ix->tielog_bytes;
     // out of memory on the handle itself: the hidden lanes' idle workspaces go first, then once more (not from inside
     // fnv_tune, which holds the lanes)
     if (rc != FNV_ERR_NO_DEVICE || attempt || ix->is_lane || ix->parent || force_variant >= 0) break;
@@ -1193,13 +1206,15 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   p.ovf_bitmap = ix->d_bitmap;
   p.ovf_glist = ix->d_ovf;
   p.cand_spill = ix->d_spill;
+  p.tie_log = ix->d_tielog;
+  if (!sorted) p.log_entries = 0u;
   p.dispenser = ix->d_dispenser;
   p.status = (int32_t*)(ix->d_dispenser + 1);
   p.redo_count = ix->d_dispenser + 3;  // [3] queries searched exactly after a tie, [4..7] by reason
   p.phase_cycles = ix->d_phase;
   p.tail_exact = multi_round && sorted ? (uint32_t)std::min<uint64_t>((uint64_t)tail_pct * nslots / 100, nq) : 0u;
 
-  HIP_TRY(hipMemsetAsync(ix->d_dispenser, 0, 8 * sizeof(uint32_t), stream));
+  HIP_TRY(hipMemsetAsync(ix->d_dispenser, 0, 16 * sizeof(uint32_t), stream));
   HIP_TRY(hipEventRecord(ix->ev0, stream));
   if (ix->entry_kernel) {
     // K0: one pass over the shared entry-scan nodes for the whole batch (LDS-staged), same stream
@@ -2057,6 +2072,21 @@ int fnv_last_replayed_queries(fnv_index_t ix, uint64_t out[5]) {
   uint32_t w[5];
   HIP_TRY(hipMemcpy(w, ix->d_dispenser + 3, sizeof(w), hipMemcpyDeviceToHost));
   for (int i = 0; i < 5; i++) out[i] = w[i];
+  return FNV_OK;
+}
+
+int fnv_last_handover_stats(fnv_index_t ix, uint64_t out[4]) {
+  if (!ix || !out) return fail(FNV_ERR_INVALID, "null argument");
+  for (int i = 0; i < 4; i++) out[i] = 0;
+  if (!ix->launched) return FNV_OK;
+  ON_DEVICE(ix->device);
+  HIP_TRY(hipStreamSynchronize(ix->last_stream));
+  uint32_t w[8];
+  HIP_TRY(hipMemcpy(w, ix->d_dispenser + 3, sizeof(w), hipMemcpyDeviceToHost));
+  out[0] = w[5];         // queries resumed from their hand-over log
+  out[1] = w[6];         // hops taken from the logs
+  out[2] = w[7];         // hops the merged-beam passes of those queries had made
+  out[3] = w[0] - w[5];  // queries searched again from scratch
   return FNV_OK;
 }
 

@@ -215,11 +215,126 @@ struct ExactCtx {
   uint32_t* ovf_list;
 };
 
+// ---------------------------------------------------------------------------------------------
+// The hand-over log (round 5).  The merged-beam kernel writes, per hop, one HEADER record {node, evaluated neighbours,
+// candidates that follow} and the row's neighbours that could still be admitted when the row began (distance < max_dist of
+// that moment, or the beam not yet full) as CANDIDATE records {distance, id} in link order -- 8 bytes each, in the slot's
+// HBM log area.  When equal keys meet at a decision, the query is not searched again from scratch: the reference's two
+// heaps are REPLAYED from the log (no vector is loaded, no distance computed, the visited set is the one the merged-beam
+// pass left), and the exact search continues from there.  Per logged hop the reference's loop head runs first
+// (Index.h:625-633): if its top is not the logged node -- equal keys, the reference expands another node first -- the replay
+// stops at that hop, the visited set is rebuilt as {entry} + every link of the nodes expanded so far (Index.h:679-684 marks
+// every link it looks at) and the exact search continues from THAT state.  By induction over the hops the replayed state is
+// the reference's: the same node is expanded against the same visited set, so the same neighbours are evaluated, and a
+// neighbour the log leaves out is refused by the reference as well (max_dist never grows once the beam is full).
+// CPU model of exactly this procedure against the oracle: oracle.replay_search, tests/test_replay_model.py.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t LOG_HDR = 0xFFC00000u;  // key bits of a header record: a NaN no distance ever is (candidates are finite)
+constexpr int LOG_MAX_LINKS = 63;          // rows of up to 63 links are logged (a hop is at most 64 records)
+__device__ __forceinline__ unsigned long long log_header(uint32_t node, uint32_t evaluated, uint32_t cands) {
+  return (unsigned long long)(LOG_HDR | (evaluated << 8) | cands) | ((unsigned long long)node << 32);
+}
+
+// Sequential reader: records [base, base + 64) live in registers (lane i: record base + i), the next 64 are requested as
+// soon as the window moves -- a replay consumes ~6 records per hop, so the load has ten hops to arrive.
+struct LogReader {
+  const unsigned long long* log;
+  uint32_t n, base;
+  unsigned long long cur, next;
+  __device__ __forceinline__ void open(const unsigned long long* l, uint32_t count, int lane) {
+    log = l;
+    n = count;
+    base = 0;
+    cur = load(min((uint32_t)lane, n - 1));
+    next = load(min(WAVE + (uint32_t)lane, n - 1));
+  }
+  // past this CU's vector L1 (which may still hold lines of this slot's log area from an earlier query's replay): the
+  // records were written by this wave moments ago and sit in the XCD's L2
+  __device__ __forceinline__ unsigned long long load(uint32_t i) const {
+    return __hip_atomic_load(log + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __device__ __forceinline__ fnv_stl::Entry get(uint32_t r, int lane) {  // r wave-uniform, base <= r < n, never moves back
+    while (r >= base + WAVE) {
+      cur = next;
+      base += WAVE;
+      next = load(min(base + WAVE + (uint32_t)lane, n - 1));
+    }
+    const int l = (int)(r - base);
+    fnv_stl::Entry e;
+    e.key = __int_as_float(__builtin_amdgcn_readlane((int)(uint32_t)cur, l));
+    e.val = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cur >> 32), l);
+    return e;
+  }
+};
+
+// The exact search's state between two admissions (wave-uniform).
+struct ExactState {
+  int nbr_n, cand_n;
+  float max_dist;
+  int err;
+};
+
+// One admission (Index.h:693-704) of (di, idi) into both heaps; the caller has checked nothing.
+__device__ __forceinline__ void exact_admit(const ExactCtx& x, LdsHeap& nbr, LdsHeap& cand, unsigned long long* spill,
+                                            ExactState& s, float di, uint32_t idi, int lane, PhaseTimer& ph) {
+  const int B = x.B, cand_slots = x.cand_slots;
+  if (!(s.nbr_n < B || di < s.max_dist)) return;  // Index.h:693
+  // max_dist == neighbors.top().first throughout (Index.h:702), so the new top is known without reading
+  // the heap back: a push changes it only if the new element climbs to the root, a pop reports it
+  bool at_root;
+  if (s.cand_n < cand_slots) {
+    at_root = coop_push2(cand, s.cand_n, fnv_stl::Entry{-di, idi}, nbr, s.nbr_n, fnv_stl::Entry{di, idi}, lane, ph, 11);
+  } else {
+    const int spill_entries = (int)cold_args()->spill_entries;
+    if (s.cand_n >= cand_slots + spill_entries) {
+      s.err = ST_CAND_OVERFLOW;
+      return;
+    }
+    CandHeap cand_big{cand.p, spill, cand_slots};
+    __threadfence_block();
+    coop_push(cand_big, s.cand_n, fnv_stl::Entry{-di, idi}, lane, ph, 11);
+    __threadfence_block();
+    at_root = coop_push(nbr, s.nbr_n, fnv_stl::Entry{di, idi}, lane, ph, 12);
+  }
+  if (at_root) s.max_dist = di;
+  if (s.nbr_n + 1 > B) s.max_dist = coop_pop<false>(nbr, s.nbr_n + 1, lane, ph, 13);
+  s.cand_n++;
+  if (s.nbr_n < B) s.nbr_n++;
+}
+
+// The candidates heap's top (Index.h:626) and its removal (:634), wherever the heap lives.
+__device__ __forceinline__ fnv_stl::Entry exact_cand_top(const ExactCtx& x, const LdsHeap& cand, const unsigned long long* spill) {
+  return x.cand_slots > 0 ? cand.get(0) : unpack(spill[0]);  // same address in every lane: broadcast
+}
+__device__ __forceinline__ void exact_cand_pop(const ExactCtx& x, LdsHeap& cand, unsigned long long* spill, ExactState& s, int lane,
+                                               PhaseTimer& ph) {
+  if (s.cand_n <= x.cand_slots) {
+    coop_pop<false>(cand, s.cand_n, lane, ph, 8);
+  } else {  // part of the heap lives in the HBM spill area
+    CandHeap cand_big{cand.p, spill, x.cand_slots};
+    __threadfence_block();
+    coop_pop<false>(cand_big, s.cand_n, lane, ph, 8);
+    __threadfence_block();
+  }
+  s.cand_n--;
+}
+
+// What a search that was RESUMED from a log starts with (the heaps are in place, the visited set is current).
+struct ExactResume {
+  ExactState s;
+  uint32_t n_dist, n_hops;
+  bool ovf;
+};
+
 // `stop` (null: never) = a word another wavefront sets once the same query has been answered (shadow mode, search_params.h):
 // polled once per hop; the search then gives up -- no results written, per-slot state left clean.
+// `resumed` (false: a search from scratch): heaps, visited set and counters come from a replayed log (`rs`); the search starts
+// at the loop head.  (A run-time flag, not a template parameter: the merged-beam kernel inlines this function ONCE for both;
+// `rs` by value: a pointer to it would keep the struct in scratch memory.)
 template <typename T, int METRIC, int G, int CU, bool FULL>
 __device__ __forceinline__ void exact_query(const ExactCtx& x, const Query<G, CU>& q, int qi, uint32_t entry, float best_d, int lane,
-                                            PhaseTimer& ph, const uint32_t* stop = nullptr) {
+                                            PhaseTimer& ph, const uint32_t* stop = nullptr, bool resumed = false,
+                                            ExactResume rs = ExactResume{ExactState{1, 1, 0.f, ST_OK}, 0u, 0u, false}) {
   // (the lane index is made opaque here: everything derived from it below -- lane masks, group indices, chunk offsets --
   // is then computed per call instead of being hoisted to the kernel entry, where the merged-beam kernel, which inlines
   // this function for its rare re-runs, would have to keep it alive across its own hop loop and spill it to scratch)
@@ -240,51 +355,46 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, const Query<G, CU
   uint32_t* const ovf_glist = cold_args()->ovf_glist + (uint64_t)blockIdx.x * cold_args()->ovf_cap;
   unsigned long long* const spill = cold_args()->cand_spill + (uint64_t)blockIdx.x * cold_args()->spill_entries;
 
-  int nbr_n = 1, cand_n = 1;
-  float max_dist = best_d;  // == distance(query, entry): same arithmetic, same bits
-  if (lane == 0) {
-    CandHeap c0{cand.p, spill, cand_slots};
-    c0.set(0, fnv_stl::Entry{-best_d, entry});
-    nbr.set(0, fnv_stl::Entry{best_d, entry});
-  }
+  ExactState s{1, 1, best_d, ST_OK};  // max_dist == distance(query, entry): same arithmetic, same bits
   uint32_t vis_count = 1;
   bool ovf = false;       // 32-bit table: switched to the bitmap; tagged: some id went to the bitmap
-  if (!tagged) {
-    if (lane == 0) visited_insert_lds(vis, cold_args()->vis_slots - 1, cold_args()->vis_shift, entry);
-  } else if (vg.w == 16) {
-    visited_insert_tag16(vis, vg, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
+  uint32_t n_dist = 0, n_hops = 0;
+  if (resumed) {
+    s = rs.s;
+    n_dist = rs.n_dist;
+    n_hops = rs.n_hops;
+    ovf = rs.ovf;
   } else {
-    visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), vg, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
+    if (lane == 0) {
+      CandHeap c0{cand.p, spill, cand_slots};
+      c0.set(0, fnv_stl::Entry{-best_d, entry});
+      nbr.set(0, fnv_stl::Entry{best_d, entry});
+    }
+    if (!tagged) {
+      if (lane == 0) visited_insert_lds(vis, cold_args()->vis_slots - 1, cold_args()->vis_shift, entry);
+    } else if (vg.w == 16) {
+      visited_insert_tag16(vis, vg, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
+    } else {
+      visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), vg, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
+    }
   }
   // (ovf is wave-uniform: the visited inserts set it for every lane)
-  int err = ST_OK;
   bool aborted = false;
-  uint32_t n_dist = 0, n_hops = 0;
   if (cand_slots == 0) __threadfence_block();
   __syncthreads();
 
   while (true) {
-    if (cand_n <= 0) break;
-    fnv_stl::Entry ctop;
-    if (cand_slots > 0) ctop = cand.get(0);  // same address in every lane: LDS broadcast
-    else ctop = unpack(spill[0]);
+    if (s.cand_n <= 0) break;
+    const fnv_stl::Entry ctop = exact_cand_top(x, cand, spill);
     const float ctop_d = -rfl(ctop.key);
-    if (ctop_d > max_dist && nbr_n >= B) break;  // Index.h:630
+    if (ctop_d > s.max_dist && s.nbr_n >= B) break;  // Index.h:630
     const int node = rfl((int)ctop.val);
     // issue the link-row load now; the cooperative pop below hides most of its HBM latency
     uint32_t row_id = EMPTY_ID;
     if (lane < M) row_id = links[(uint64_t)(uint32_t)node * (uint32_t)M + lane];
     uint32_t stop_now = 0u;  // (read past this CU's L1: another CU writes it)
     if (stop) stop_now = __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cand_n <= cand_slots) {
-      coop_pop<false>(cand, cand_n, lane, ph, 8);
-    } else {  // part of the heap lives in the HBM spill area
-      CandHeap cand_big{cand.p, spill, cand_slots};
-      __threadfence_block();
-      coop_pop<false>(cand_big, cand_n, lane, ph, 8);
-      __threadfence_block();
-    }
-    cand_n--;
+    exact_cand_pop(x, cand, spill, s, lane, ph);
     n_hops++;
     PH_MARK(2);
     if (stop && rfl((int)stop_now) == (int)SH_ANSWERED) {  // the merged-beam pass has answered this query
@@ -346,48 +456,28 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, const Query<G, CU
 #pragma unroll
         for (int pu = 0; pu < PU; pu++) {
           if (pu >= npass) break;
-          unsigned long long pm = __ballot(group_leader && cval[pu] && (nbr_n < B || cd[pu] < max_dist));
+          unsigned long long pm = __ballot(group_leader && cval[pu] && (s.nbr_n < B || cd[pu] < s.max_dist));
           while (pm) {
             const int i = __ffsll((long long)pm) - 1;
             pm &= pm - 1;
             const float di = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cd[pu]), i));
             const uint32_t idi = (uint32_t)__builtin_amdgcn_readlane((int)cid[pu], i);
-            if (nbr_n < B || di < max_dist) {  // Index.h:693
-              // max_dist == neighbors.top().first throughout (Index.h:702), so the new top is known without reading
-              // the heap back: a push changes it only if the new element climbs to the root, a pop reports it
-              bool at_root;
-              if (cand_n < cand_slots) {
-                at_root = coop_push2(cand, cand_n, fnv_stl::Entry{-di, idi}, nbr, nbr_n, fnv_stl::Entry{di, idi}, lane, ph, 11);
-              } else {
-                const int spill_entries = (int)cold_args()->spill_entries;
-                if (cand_n >= cand_slots + spill_entries) {
-                  err = ST_CAND_OVERFLOW;
-                  pm = 0;
-                  break;
-                }
-                CandHeap cand_big{cand.p, spill, cand_slots};
-                __threadfence_block();
-                coop_push(cand_big, cand_n, fnv_stl::Entry{-di, idi}, lane, ph, 11);
-                __threadfence_block();
-                at_root = coop_push(nbr, nbr_n, fnv_stl::Entry{di, idi}, lane, ph, 12);
-              }
-              if (at_root) max_dist = di;
-              if (nbr_n + 1 > B) max_dist = coop_pop<false>(nbr, nbr_n + 1, lane, ph, 13);
-              cand_n++;
-              if (nbr_n < B) nbr_n++;
-            }
+            exact_admit(x, nbr, cand, spill, s, di, idi, lane, ph);
+            if (s.err) pm = 0;
           }
-          if (err) break;
+          if (s.err) break;
         }
         PH_MARK(6);
-        if (err) break;
+        if (s.err) break;
       }
       wave_sync();  // stage_ids is rewritten by the next row chunk
-      if (err) break;
+      if (s.err) break;
     }
-    if (err) break;
+    if (s.err) break;
   }
   PH_MARK(2);
+  const int err = s.err;
+  const int nbr_n = s.nbr_n;
 
   // Shadow mode: a shadow that ran out of candidate-heap room AFTER the merged-beam pass answered the query has nothing to
   // report either -- the launch-wide status word must not fail a launch whose every query was answered.  (What remains: a
@@ -475,6 +565,101 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, const Query<G, CU
   PH_MARK(7);
   if (ovf) clear_spill_bitmap(bitmap, ovf_list, ovf_glist, tagged, lane);
   __syncthreads();
+}
+
+// Replays the slot's hand-over log (`records` records, see above) into the reference's two heaps and leaves in `out` the
+// state from which exact_query<..., RESUME> continues.  `ovf`: whether the merged-beam pass sent ids to the HBM bitmap.  The
+// visited set is left as the merged-beam pass had it when every logged hop was the reference's; else it is rebuilt for the
+// hops that were.  Returns the number of hops taken from the log.
+__device__ __forceinline__ uint32_t replay_log(const ExactCtx& x, const unsigned long long* log, uint32_t records, uint32_t entry,
+                                               float best_d, bool ovf, int lane, PhaseTimer& ph, ExactResume& out) {
+  asm volatile("" : "+v"(lane));
+  const int B = x.B, M = x.M;
+  LdsHeap nbr{x.nbr};
+  LdsHeap cand{x.cand};
+  unsigned long long* const spill = cold_args()->cand_spill + (uint64_t)blockIdx.x * cold_args()->spill_entries;
+  ExactState s{1, 1, best_d, ST_OK};
+  if (lane == 0) {
+    CandHeap c0{cand.p, spill, x.cand_slots};
+    c0.set(0, fnv_stl::Entry{-best_d, entry});
+    nbr.set(0, fnv_stl::Entry{best_d, entry});
+  }
+  if (x.cand_slots == 0) __threadfence_block();
+  __syncthreads();
+  uint32_t pos = 0, hops = 0, n_dist = 0;
+  bool all = true;  // every logged hop was the reference's
+  if (records > 0) {
+    LogReader rd;
+    rd.open(log, records, lane);
+    while (pos < records) {
+      const fnv_stl::Entry h = rd.get(pos, lane);
+      const uint32_t hb = __float_as_uint(h.key);
+      const uint32_t nc = hb & 0xFFu, evaluated = (hb >> 8) & 0x3FFFu;
+      // the reference's loop head (Index.h:625-633)
+      bool mine = s.cand_n > 0;
+      if (mine) {
+        const fnv_stl::Entry ctop = exact_cand_top(x, cand, spill);
+        const float ctop_d = -rfl(ctop.key);
+        mine = !(ctop_d > s.max_dist && s.nbr_n >= B) && (uint32_t)rfl((int)ctop.val) == h.val;
+      }
+      if (!mine) {  // equal keys: the reference expands another node first (or would stop) -- the log ends here
+        all = false;
+        break;
+      }
+      exact_cand_pop(x, cand, spill, s, lane, ph);
+      hops++;
+      n_dist += evaluated;
+      for (uint32_t i = 1; i <= nc; i++) {
+        const fnv_stl::Entry c = rd.get(pos + i, lane);
+        exact_admit(x, nbr, cand, spill, s, c.key, c.val, lane, ph);
+        if (s.err) break;
+      }
+      if (s.err) break;
+      pos += 1 + nc;
+    }
+  }
+  if (!all && !s.err) {
+    // Rebuild the visited set for the hops that were taken: {entry} + every link of their nodes.  (The rows are L2 hits more
+    // often than not -- the merged-beam pass has just read them -- and row k + 1 is requested before row k is inserted.)
+    uint32_t* const vis = x.vis;
+    uint32_t* const ovf_list = x.ovf_list;
+    uint32_t* const bitmap = cold_args()->ovf_bitmap + (uint64_t)blockIdx.x * cold_args()->bitmap_words;
+    uint32_t* const ovf_glist = cold_args()->ovf_glist + (uint64_t)blockIdx.x * cold_args()->ovf_cap;
+    if (ovf) clear_spill_bitmap(bitmap, ovf_list, ovf_glist, true, lane);
+    reset_visited(vis, ovf_list, true, lane);
+    __syncthreads();
+    ovf = false;
+    const VisGeom vg = x.vg;
+    auto insert = [&](bool act, uint32_t id) {
+      if (vg.w == 16) visited_insert_tag16(vis, vg, act, id, bitmap, ovf_list, ovf_glist, ovf);
+      else visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), vg, act, id, bitmap, ovf_list, ovf_glist, ovf);
+    };
+    insert(lane == 0, entry);
+    if (hops > 0) {
+      LogReader rd;
+      rd.open(log, records, lane);
+      uint32_t p2 = 0;
+      auto row_of = [&](uint32_t node) -> uint32_t { return lane < M ? x.links[(uint64_t)node * (uint32_t)M + lane] : EMPTY_ID; };
+      fnv_stl::Entry h = rd.get(0, lane);
+      uint32_t row = row_of(h.val);
+      for (uint32_t k = 0; k < hops; k++) {
+        p2 += 1 + (__float_as_uint(h.key) & 0xFFu);
+        uint32_t next_row = EMPTY_ID;
+        if (k + 1 < hops) {
+          h = rd.get(p2, lane);
+          next_row = row_of(h.val);
+        }
+        insert(lane < M, row);
+        row = next_row;
+      }
+    }
+    wave_sync();
+  }
+  out.s = s;
+  out.n_dist = n_dist;
+  out.n_hops = hops;
+  out.ovf = ovf;
+  return hops;
 }
 
 template <typename T, int METRIC, int G, int CU, bool FULL>

@@ -198,6 +198,15 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : R == MB_R ? 3 : waves_per_simd<
     float pend = -INF;  // (b) pending: largest key at which two unexpanded members tied
     bool pend_cut = false;  // ... and, while it is pending, equal keys met where the beam is cut (see the header)
     uint32_t n_dist = 0, n_hops = 0;
+    // Round 5: the hand-over log (kernels.hpp): one header + the row's admissible neighbours per hop, in the slot's HBM log
+    // area.  Off (log_cap = 0) when the launch has no log area, for rows wider than LOG_MAX_LINKS and for work items that
+    // go straight to the exact search; a log that would overflow stops (the query is then searched again from scratch).
+    // (nor for queries that have an exact shadow -- every query of a small launch: the shadow answers the tied ones, and a lone
+    //  wave's hop is 3.5 % longer with the log's two stores: r5_run4)
+    uint32_t log_n = 0;
+    const bool shadowed = shadow_base != 0u && (uint32_t)qi + (ca->nq - shadow_base) >= shadow_base;
+    uint32_t log_cap = (tie || M > LOG_MAX_LINKS || shadowed) ? 0u : ca->log_entries;
+    unsigned long long* const tie_log = ca->tie_log + (uint64_t)blockIdx.x * ca->log_entries;
     // Round 3: the link row of the RUNNER-UP is requested one hop ahead.  Once the beam has converged the next node to
     // expand is most often the current runner-up (a new neighbour rarely lands in front of every unexpanded member), and
     // then the hop starts with its link row already in a register: one dependent memory round trip per hop instead of
@@ -306,7 +315,14 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : R == MB_R ? 3 : waves_per_simd<
         stage_ids[isnew ? __popcll(newmask & ((1ull << lane) - 1ull)) : WAVE] = id;  // keeps link order
         wave_sync();
         PH_MARK(4);
-        if (nn == 0) return true;
+        if (log_cap != 0u && log_n + 1u + (uint32_t)WAVE > log_cap) log_cap = 0u;  // no room for another hop: the log ends here
+        if (nn == 0) {
+          if (log_cap != 0u) {
+            if (lane == 0) tie_log[log_n] = log_header((uint32_t)node, 0u, 0u);
+            log_n++;
+          }
+          return true;
+        }
         n_dist += nn;
 
         // ---- distances of the row's unvisited neighbours, staged in link order ----------------------------------
@@ -342,11 +358,18 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : R == MB_R ? 3 : waves_per_simd<
         // (b) while a selection tie is pending the order of the tied expansions is the reference's choice; a neighbour
         // refused exactly at the cut (d == max_dist) would have been kept had its row come first
         if (pend > -INF && full0 && (__ballot(d == max_dist) & nnmask) != 0ull) pend_cut = true;
+        if (pm != 0ull && (__ballot(!(d < INF)) & pm) != 0ull) {  // NaN / infinite distance that could be admitted
+          tie = 4;
+          return false;
+        }
+        if (log_cap != 0u) {  // header, then the candidates that could still be admitted, in link order
+          const uint32_t cl = (uint32_t)__popcll(pm);
+          if (((pm >> lane) & 1ull) != 0ull)
+            tie_log[log_n + 1u + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = pack(fnv_stl::Entry{d, cand_id});
+          if (lane == 0) tie_log[log_n] = log_header((uint32_t)node, (uint32_t)nn, cl);
+          log_n += 1u + cl;
+        }
         if (pm != 0ull) {
-          if ((__ballot(!(d < INF)) & pm) != 0ull) {  // NaN / infinite distance that could be admitted
-            tie = 4;
-            return false;
-          }
           const bool pass = ((pm >> lane) & 1ull) != 0ull;
           const int c = __popcll(pm);
           const unsigned long long key64 = ((unsigned long long)float_ord(d) << 32) | (uint32_t)lane;
@@ -528,13 +551,17 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : R == MB_R ? 3 : waves_per_simd<
         }
       }
     }
-    if (tie) {  // search this query again, exactly (results, counters and clean-up are exact_query's)
+    if (tie) {  // equal keys met at a decision: the exact search takes over (results, counters and clean-up are exact_query's)
+      // Round 5: not from scratch -- the reference's heaps are replayed from this query's log and the exact search continues
+      // where the merged-beam pass stopped (kernels.hpp).  From scratch only: no / an overflowed log, a NaN / infinite distance
+      // (the row was marked visited but not logged), work items that never ran the merged-beam pass.
+      const bool resume = tie < 4 && log_cap != 0u;
       if (lane == 0 && tie < 5) {
         uint32_t* rc = c->redo_count;
         atomicAdd(rc, 1u);
         atomicAdd(rc + tie, 1u);
       }
-      if (ovf) clear_spill_bitmap(bitmap, ovf_list, ovf_glist, true, lane);
+      if (ovf && !resume) clear_spill_bitmap(bitmap, ovf_list, ovf_glist, true, lane);
       // a query in the shadowed range: whoever claims it first searches it exactly -- a shadow that is already under way
       // (then this wave moves on: the answer comes one exact-search latency after the QUERY started, not after this pass
       // ended), else this wave itself (and no shadow will start on it any more)
@@ -542,12 +569,13 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : R == MB_R ? 3 : waves_per_simd<
         uint32_t old = 0u;
         if (lane == 0) old = atomicCAS(c->done_flags + qi, SH_NONE, SH_OWN_RERUN);
         if (rfl((int)old) == (int)SH_SHADOW) {
+          if (ovf && resume) clear_spill_bitmap(bitmap, ovf_list, ovf_glist, true, lane);
           PH_FLUSH;
           __syncthreads();
           continue;
         }
       }
-      reset_visited(vis, ovf_list, true, lane);
+      if (!resume) reset_visited(vis, ovf_list, true, lane);
       __syncthreads();
       ColdArgs xa = cold_args();
       ExactCtx x;
@@ -565,7 +593,18 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : R == MB_R ? 3 : waves_per_simd<
       x.vis = reinterpret_cast<uint32_t*>(smem + xa->off_vis);
       x.stage_ids = reinterpret_cast<uint32_t*>(smem + xa->off_stage_ids);
       x.ovf_list = reinterpret_cast<uint32_t*>(smem + xa->off_ovf);
-      exact_query<T, METRIC, G, CU, FULL>(x, q, qi, entry, best_d, lane, ph, shadow ? xa->done_flags + qi : nullptr);
+      ExactResume rs{ExactState{1, 1, 0.f, ST_OK}, 0u, 0u, false};
+      if (resume) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the log's stores have left this wave (the reader loads past the L1)
+        const uint32_t taken = replay_log(x, xa->tie_log + (uint64_t)blockIdx.x * xa->log_entries, log_n, entry, best_d, ovf, lane, ph, rs);
+        if (lane == 0) {  // [5] queries resumed from their log, [6] hops taken from the logs, [7] hops the merged-beam passes had made
+          uint32_t* rc = xa->redo_count;
+          atomicAdd(rc + 5, 1u);
+          atomicAdd(rc + 6, taken);
+          atomicAdd(rc + 7, n_hops);
+        }
+      }
+      exact_query<T, METRIC, G, CU, FULL>(x, q, qi, entry, best_d, lane, ph, shadow ? xa->done_flags + qi : nullptr, resume, rs);
 #ifdef FNV_TIMELINE  // bits 60-61 of the end reading: 1 = searched twice (equal keys), 2 = sent straight to the exact search
       if (lane == 0 && !shadow && xa->out_ndist && xa->out_nhops) {
         xa->out_ndist[qi] = tl_start;

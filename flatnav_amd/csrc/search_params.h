@@ -73,8 +73,9 @@ struct SearchParams {
   uint64_t* out_ndist;      // [nq] or null
   uint64_t* out_nhops;      // [nq] or null
   uint32_t* dispenser;      // next query id
-  uint32_t* redo_count;     // merged-beam kernel: [0] queries it searched again exactly (equal keys at a decision),
-                            // [1..4] by reason
+  uint32_t* redo_count;     // merged-beam kernel: [0] queries it handed to the exact search (equal keys at a decision),
+                            // [1..4] by reason, [5] of them resumed from their log, [6] hops taken from the logs,
+                            // [7] hops the merged-beam passes of the resumed queries had made
   int32_t* status;          // sticky error flag for the whole launch
   uint32_t* ovf_bitmap;     // [nslots][bitmap_words] visited-set spill (all zero between queries)
   uint32_t* ovf_glist;      // [nslots][ovf_cap] ids sent to the bitmap beyond the first OVF_LIST (big indexes only)
@@ -117,6 +118,10 @@ struct SearchParams {
   // exact-search latency from the query's start, paid by a slot that had nothing else to do.  0 = off.
   uint32_t shadow_base;
   uint32_t* done_flags;
+  // Round 5: the hand-over log of the merged-beam kernel (kernels.hpp): log_entries 8-byte records per slot (0: no log --
+  // a query in which equal keys meet at a decision is then searched again from scratch, as in rounds 2-4)
+  unsigned long long* tie_log;  // [nslots][log_entries]
+  uint32_t log_entries;
 };
 
 // Broadcast of lane 0's value into a scalar register ("this value is wave-uniform").

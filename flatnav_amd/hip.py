@@ -26,7 +26,7 @@ C_ABI_SYMBOLS = [
     "fnv_index_set_live_nodes", "fnv_index_write_nodes", "fnv_index_write_links", "fnv_index_insert_batch",
     "fnv_index_read_links", "fnv_last_replayed_queries", "fnv_replicate", "fnv_replica_refresh",
     "fnv_search_batch_multi", "fnv_index_view", "fnv_tune", "fnv_last_launch_info", "fnv_gather_ceiling",
-    "fnv_index_adopt", "fnv_lane_info",
+    "fnv_index_adopt", "fnv_lane_info", "fnv_last_handover_stats",
 ]
 
 _lib = None
@@ -84,6 +84,7 @@ def lib() -> C.CDLL:
     L.fnv_last_launch_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.fnv_gather_ceiling.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
     L.fnv_lane_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.fnv_last_handover_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -320,6 +321,13 @@ class DeviceIndex:
         r = (C.c_uint64 * 5)()
         check(lib().fnv_last_replayed_queries(self._h, r))
         return dict(zip(["total", "eviction_tie", "selection_tie", "result_tie", "nan_inf"], [int(x) for x in r]))
+
+    def handover_stats(self) -> dict:
+        """Hand-overs of the last search (fnv_last_handover_stats): queries resumed from their log, hops taken from the logs,
+        hops those queries' merged-beam passes had made, queries searched again from scratch."""
+        r = (C.c_uint64 * 4)()
+        check(lib().fnv_last_handover_stats(self._h, r))
+        return dict(zip(["resumed", "hops_from_log", "hops_of_resumed", "from_scratch"], [int(x) for x in r]))
 
     def launch_geometry(self) -> dict:
         g = (C.c_uint64 * 8)()

@@ -195,6 +195,10 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *                     the same query on another slot; a query in which equal distances meet at a decision is then
  *                     answered after one exact-search latency from the start of the launch instead of a merged-beam pass
  *                     plus a re-run, the shadow of a query that needs none stops at its next hop.  0 = off.  Same bytes.
+ *   "tie_replay"      1 (default): a query in which equal distances meet at a decision is resumed from its hand-over log
+ *                     (fnv_last_handover_stats) instead of being searched again from scratch; 0 = from scratch, as in
+ *                     rounds 2-4.  "tie_log_entries": 8-byte log records per resident query slot in HBM (0 = automatic:
+ *                     24 per beam entry + 512, in [1024, 16384]).  Same bytes.
  *   "tune_layout"     1 (default): fnv_tune also measures the LDS layout (see fnv_tune); 0 = kernel variants only
  *   "sorted_beam_min" smallest beam width the merged-beam kernel is used for (default 1)
  *   "sorted_cand_lds" where the exact re-run of the merged-beam kernel keeps its candidates heap: 2 (default) = in LDS
@@ -306,6 +310,15 @@ int fnv_last_launch_geometry(fnv_index_t index, uint64_t geom[8]);
 int fnv_tune(fnv_index_t index, const void* queries, uint64_t nq, int queries_on_device, int K, int ef_search,
              int num_initializations);
 int fnv_last_launch_info(fnv_index_t index, uint64_t info[4]);
+
+/* The merged-beam kernel's hand-overs of the most recent launch (round 5).  A query in which equal distances meet at a decision
+ * (fnv_last_replayed_queries counts them by reason) is not searched again from scratch: the reference's two heaps
+ * (Index.h:618-619) are replayed from a log the merged-beam pass wrote -- per hop the expanded node and the neighbours that could
+ * still be admitted -- and the exact search continues where that pass stopped; if the reference would have expanded another
+ * node of equal distance first, from that hop.  out[0] = queries resumed from their log, out[1] = hops taken from the logs,
+ * out[2] = hops the merged-beam passes of those queries had made, out[3] = queries searched again from scratch (no / an
+ * overflowed log: options "tie_replay" = 0, "tie_log_entries"; NaN / infinite distances).  Same bytes either way. */
+int fnv_last_handover_stats(fnv_index_t index, uint64_t out[4]);
 
 /* What the handle (i = 0) and its hidden lanes (i = 1 ... 7; see fnv_search_batch) hold and did: info[2 i] = bytes of launch
  * workspace in HBM (visited bitmaps, overflow lists, candidate spill areas), info[2 i + 1] = launches that were exploratory

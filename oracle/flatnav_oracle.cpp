@@ -621,6 +621,94 @@ int orc_replay_neighbors(const float* d, const uint32_t* ids, uint64_t n, int bu
   ORC_CATCH
 }
 
+// Design check for the GPU's mid-flight hand-over (round 5; csrc/kernels.hpp `resume_from_log`): the reference's search
+// RESUMED from a log that the merged-beam traversal wrote.  The log is a stream of records: a hop header {node, number of
+// neighbours evaluated} followed by that hop's evaluated neighbours that could still be admitted when the row began
+// (distance < max_dist of that moment, or the beam not yet full), in link order.  Both heaps are the real
+// std::priority_queue: per logged hop the reference's loop head runs (Index.h:625-633) -- if its top is NOT the logged node
+// (equal keys: the reference expands another node first) the replay stops THERE --, then the logged neighbours go through
+// the reference's admission (Index.h:693-704).  The visited set is then rebuilt as {entry} + every link of the nodes
+// expanded so far (Index.h:679-684 marks every link it looks at), and the reference's own loop continues from that state
+// with real distances.  is_hdr[i] != 0: record i is a header (ids[i] = node, d[i] = evaluated count as a float).
+int orc_replay_search(void* h, const void* query, int K, int ef, uint32_t entry, const float* d, const uint32_t* ids,
+                      const uint8_t* is_hdr, uint64_t n, float* out_d, int32_t* out_l, int32_t* out_count,
+                      uint64_t* ndist, uint64_t* nhops, uint64_t* hops_replayed) {
+  ORC_TRY
+  Index* ix = (Index*)h;
+  const size_t B = (size_t)std::max(ef, K);
+  PriorityQueue neighbors, candidates;
+  const float d0 = ix->dist(query, ix->nodeData(entry), ix->dim);
+  float max_dist = d0;
+  candidates.emplace(-d0, entry);
+  neighbors.emplace(d0, entry);
+  std::vector<node_id_t> expanded;
+  uint64_t n_dist = 0, n_hops = 0, pos = 0;
+  while (pos < n) {
+    if (!is_hdr[pos]) throw std::runtime_error("log: header expected");
+    if (candidates.empty()) break;
+    dist_node_t top = candidates.top();
+    if (-top.first > max_dist && neighbors.size() >= B) break;  // (the reference would stop; cannot happen for a beam member)
+    if (top.second != ids[pos]) break;                          // equal keys: the reference expands another node first
+    candidates.pop();
+    n_hops++;
+    n_dist += (uint64_t)d[pos];
+    expanded.push_back(ids[pos]);
+    pos++;
+    for (; pos < n && !is_hdr[pos]; pos++) {
+      if (neighbors.size() < B || d[pos] < max_dist) {  // Index.h:693
+        candidates.emplace(-d[pos], ids[pos]);
+        neighbors.emplace(d[pos], ids[pos]);
+        if (neighbors.size() > B) neighbors.pop();
+        if (!neighbors.empty()) max_dist = neighbors.top().first;
+      }
+    }
+  }
+  if (hops_replayed) *hops_replayed = n_hops;
+  VisitedSet visited(ix->max_nodes);
+  visited.clear();
+  visited.insert(entry);
+  for (node_id_t e : expanded) {
+    node_id_t* links = ix->nodeLinks(e);
+    for (uint32_t i = 0; i < ix->M; i++) visited.insert(links[i]);
+  }
+  while (!candidates.empty()) {  // Index.h:625-659 from the replayed state
+    dist_node_t top = candidates.top();
+    if (-top.first > max_dist && neighbors.size() >= B) break;
+    candidates.pop();
+    n_hops++;
+    node_id_t* links = ix->nodeLinks(top.second);
+    for (uint32_t i = 0; i < ix->M; i++) {
+      node_id_t nb = links[i];
+      if (visited.isVisited(nb)) continue;
+      visited.insert(nb);
+      float dd = ix->dist(query, ix->nodeData(nb), ix->dim);
+      n_dist++;
+      if (neighbors.size() < B || dd < max_dist) {
+        candidates.emplace(-dd, nb);
+        neighbors.emplace(dd, nb);
+        if (neighbors.size() > B) neighbors.pop();
+        if (!neighbors.empty()) max_dist = neighbors.top().first;
+      }
+    }
+  }
+  std::vector<dist_label_t> results;
+  while (!neighbors.empty()) {
+    dist_node_t t = neighbors.top();
+    results.emplace_back(t.first, *ix->nodeLabel(t.second));
+    neighbors.pop();
+  }
+  std::sort(results.begin(), results.end(), [](const dist_label_t& l, const dist_label_t& r) { return l.first < r.first; });
+  if (results.size() > (size_t)K) results.resize(K);
+  for (size_t k = 0; k < results.size(); k++) {
+    out_d[k] = results[k].first;
+    out_l[k] = results[k].second;
+  }
+  *out_count = (int32_t)results.size();
+  if (ndist) *ndist = n_dist;
+  if (nhops) *nhops = n_hops;
+  ORC_CATCH
+}
+
 int orc_save(void* h, const char* path) {
   ORC_TRY
   save_index(*(Index*)h, path);

@@ -55,6 +55,9 @@ def lib() -> C.CDLL:
         ] * 7
         L.orc_replay_neighbors.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                            C.POINTER(C.c_int32)]
+        L.orc_replay_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
+                                        C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.orc_save.argtypes = [C.c_void_p, C.c_char_p]
         L.orc_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
         L.orc_from_blob.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
@@ -205,6 +208,19 @@ class OracleIndex:
         if stats:
             return d, l, {"count": cnt, "n_dist": st[0], "n_hops": st[1], "n_admit": st[2], "max_cand": st[3]}
         return d, l
+
+    def replay_search(self, query, K: int, ef_search: int, entry: int, log_d, log_ids, log_is_header):
+        """The reference's search resumed from a traversal log (orc_replay_search: a design check for the GPU's mid-flight
+        hand-over).  -> (dists[<=K], labels[<=K], n_dist, n_hops, hops taken from the log)"""
+        q = np.ascontiguousarray(query, dtype=_np_dtype(self.dtype))
+        d = np.ascontiguousarray(log_d, dtype=np.float32)
+        i = np.ascontiguousarray(log_ids, dtype=np.uint32)
+        hdr = np.ascontiguousarray(log_is_header, dtype=np.uint8)
+        od, ol, cnt = np.empty(K, dtype=np.float32), np.empty(K, dtype=np.int32), C.c_int32(0)
+        nd, nh, rep = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _check(lib().orc_replay_search(self._h, q.ctypes.data, K, ef_search, entry, d.ctypes.data, i.ctypes.data, hdr.ctypes.data,
+                                       len(d), od.ctypes.data, ol.ctypes.data, C.byref(cnt), C.byref(nd), C.byref(nh), C.byref(rep)))
+        return od[:cnt.value], ol[:cnt.value], nd.value, nh.value, rep.value
 
     def save(self, path: str) -> None:
         _check(lib().orc_save(self._h, path.encode()))

@@ -16,9 +16,12 @@ SMALL = ["--index-size", "60000", "--nq", "2000", "--steps", "2", "--warmup", "1
 def _last_json(out):
     """stdout carries exactly ONE line, the contract line, at most 4 KB (BENCH_r04.json: a 25 KB line was not parsed)."""
     lines = [l for l in out.splitlines() if l.strip()]
-    assert len(lines) == 1 and lines[0].startswith("{"), out[-3000:]
-    assert len(lines[0].encode()) <= 4096, len(lines[0])
-    return json.loads(lines[0])
+    # (the gloo backend of the two-rank tests prints "[Gloo] Rank ... is connected to ..." lines of its own to stdout, the
+    #  two ranks' interleaved; RCCL does not) -- bench.py's own output is ONE line, and it is the last one
+    ours = [l for l in lines if l.startswith("{")]
+    assert len(ours) == 1 and lines[-1] == ours[0] and all("connected to" in l for l in lines[:-1]), out[-3000:]
+    assert len(ours[0].encode()) <= 4096, len(ours[0])
+    return json.loads(ours[0])
 
 
 def _run(cmd, tmp_path, env=None, timeout=900):

@@ -153,3 +153,109 @@ def test_lanes_never_explore(oracle_mod, hipmod):
     explored = hipmod.lane_exploratory_launches(dev)
     assert explored[0] >= 0 and all(e == 0 for e in explored[1:]), explored
     dev.close()
+
+
+@pytest.mark.parametrize("case", ["u8_dense_ties", "u8_ties", "sift_f32", "i8_ip"])
+def test_tied_queries_are_resumed_from_their_log(oracle_mod, hipmod, case):
+    # The mid-flight hand-over (csrc/kernels.hpp `replay_log`): a query in which equal keys meet at a decision is not
+    # searched again from scratch -- the reference's two heaps are replayed from the log the merged-beam pass wrote and
+    # the exact search continues from there (from the hop where the reference would have expanded another node of equal
+    # distance first, with the visited set rebuilt for the hops before it).  ids, distance bits, counts and the per-query
+    # counters equal the oracle's in every beam form and heap home, with the log on, off and overflowing.
+    rng = np.random.default_rng(5)
+    if case == "u8_dense_ties":  # every query ties, early and often: most hand-overs rewind
+        X = rng.integers(0, 4, (8000, 16)).astype(np.uint8); Q = rng.integers(0, 4, (500, 16)).astype(np.uint8)
+        metric, dt, M = "l2", "uint8", 16
+    elif case == "u8_ties":  # about half the queries tie
+        X = rng.integers(0, 16, (8000, 32)).astype(np.uint8); Q = rng.integers(0, 16, (500, 32)).astype(np.uint8)
+        metric, dt, M = "l2", "uint8", 16
+    elif case == "sift_f32":  # integer-valued floats: a few per cent, late in the search -- the bench's case
+        X, Q = ds.sift_like(20000, 1500); metric, dt, M = "l2", "float32", 32
+    else:
+        X = rng.integers(-20, 20, (6000, 40)).astype(np.int8); Q = rng.integers(-20, 20, (400, 40)).astype(np.int8)
+        metric, dt, M = "ip", "int8", 16
+    ix = oracle_mod.OracleIndex.create(metric, X.shape[1], len(X), M, dt)
+    ix.add(X, 48)
+    dev = _upload(hipmod, ix)
+    dev.set_option("sorted_beam", 1)
+    dev.set_option("sorted_variant", 1)  # the merged-beam kernel for every query, no exact tail
+    dev.set_option("shadow_exact", 0)    # (launches this small would otherwise start an exact shadow next to every query, which answers the tied ones)
+    total_resumed = 0
+    for K, ef in ((10, 52), (10, 100), (1, 8), (64, 64), (10, 129), (10, 200), (10, 300), (30, 700)):
+        want = ix.search(Q, K, ef, stats=True, threads=8)
+        for regs, cand_lds in ((1, 2), (1, 0), (0, 2), (0, 0)):
+            dev.set_option("beam_registers", regs)
+            dev.set_option("sorted_cand_lds", cand_lds)
+            what = "%s K=%d ef=%d regs=%d heap home %d" % (case, K, ef, regs, cand_lds)
+            dev.set_option("tie_replay", 1)
+            dev.set_option("tie_log_entries", 0)
+            _assert_exact(want, dev.search(Q, K, ef, stats=True), what)
+            r, h = dev.replayed_queries(), dev.handover_stats()
+            assert h["resumed"] + h["from_scratch"] == r["total"] and r["nan_inf"] == 0, (what, r, h)
+            # (every hand-over resumes from its log unless the log overflowed: where many distances are equal a tied query
+            #  expands hundreds to thousands of nodes more than its beam width suggests -- the automatic log size is made for
+            #  data like the bench's, where it never overflows; the tie-dense cases resume with the largest log, below)
+            assert h["from_scratch"] == 0 or case != "sift_f32", (what, r, h)
+            assert h["hops_from_log"] <= h["hops_of_resumed"], (what, h)
+            total_resumed += h["resumed"]
+            if case == "sift_f32" and h["resumed"]:  # ties are rare and late: nearly every hop comes from the log
+                assert h["hops_from_log"] >= 0.25 * h["hops_of_resumed"], (what, h)
+            dev.set_option("tie_replay", 0)  # as in rounds 2-4: searched again from scratch
+            _assert_exact(want, dev.search(Q, K, ef, stats=True), what + ", no replay")
+            h0 = dev.handover_stats()
+            assert h0["resumed"] == 0 and h0["from_scratch"] == r["total"], (what, h0)
+            dev.set_option("tie_replay", 1)
+            dev.set_option("tie_log_entries", 16384)  # the largest log
+            _assert_exact(want, dev.search(Q, K, ef, stats=True), what + ", largest log")
+            total_resumed += dev.handover_stats()["resumed"]
+            dev.set_option("tie_log_entries", 130)  # two hops' worth: the log ends early, those queries start again
+            _assert_exact(want, dev.search(Q, K, ef, stats=True), what + ", tiny log")
+            h1 = dev.handover_stats()
+            assert h1["resumed"] + h1["from_scratch"] == r["total"], (what, h1)
+    assert total_resumed > (1000 if case.startswith("u8") else 20), total_resumed
+    print("%s: %d hand-overs resumed from their logs" % (case, total_resumed))
+    # the visited set overflows into the stash and the HBM bitmap during the merged-beam pass: a rewind has to give the
+    # bitmap back clean before it rebuilds the set (16-, 21- and 32-bit tags)
+    dev.set_option("tie_log_entries", 0)
+    dev.set_option("beam_registers", 1)
+    dev.set_option("sorted_cand_lds", 2)
+    for bits in (0, 21, 32):
+        dev.set_option("visited_tag_bits", bits)
+        for slots in (256, 384):
+            dev.set_option("visited_slots", slots)
+            for K, ef in ((10, 250), (10, 60)):
+                want = ix.search(Q, K, ef, stats=True, threads=8)
+                _assert_exact(want, dev.search(Q, K, ef, stats=True), "%s tags %d slots %d ef %d" % (case, bits, slots, ef))
+                _assert_exact(want, dev.search(Q, K, ef, stats=True), "%s tags %d slots %d ef %d, again (bitmaps clean?)" % (case, bits, slots, ef))
+    dev.close()
+
+
+def test_handover_in_a_full_launch_and_in_small_ones(oracle_mod, hipmod):
+    # the bench shape in small: more queries than slots (rounds, an exact tail of every length, the adaptive choice after
+    # fnv_tune), and launches of 1 ... 300 queries (shadow mode on and off) -- every variant returns the oracle's bytes with
+    # the hand-over log on
+    X, Q = ds.sift_like(30000, 9000)
+    Xu, Qu = X.astype(np.uint8), Q.astype(np.uint8)
+    for dt, XX, QQ in (("float32", X, Q), ("uint8", Xu, Qu)):
+        ix = oracle_mod.OracleIndex.create("l2", 128, len(XX), 32, dt)
+        ix.add(XX, 64, threads=1)
+        dev = _upload(hipmod, ix)
+        dev.set_option("blocks_per_cu", 4)  # 1024 slots: 9000 queries are nine rounds
+        K, ef = 10, 52
+        want = ix.search(QQ, K, ef, stats=True, threads=8)
+        for variant in (1, 2, 3, 4, 5, 6, 0, -1):
+            dev.set_option("sorted_variant", variant)
+            if variant == -1:
+                dev.tune(QQ[:4096], K, ef)
+            _assert_exact(want, dev.search(QQ, K, ef, stats=True), "%s variant %d" % (dt, variant))
+            if variant == 1:
+                r, h = dev.replayed_queries(), dev.handover_stats()
+                assert h["resumed"] == r["total"] > 0 and h["from_scratch"] == 0, (r, h)
+        dev.set_option("blocks_per_cu", 0)
+        for shadow in (1, 0):
+            dev.set_option("shadow_exact", shadow)
+            for nq in (1, 7, 64, 300):
+                got = dev.search(QQ[:nq], K, ef, stats=True)
+                _assert_exact(tuple(a[:nq] if not isinstance(a, dict) else {k: v[:nq] for k, v in a.items()} for a in want), got,
+                              "%s %d queries, shadow %d" % (dt, nq, shadow))
+        dev.close()

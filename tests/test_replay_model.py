@@ -47,6 +47,7 @@ def model_search(X, links, q, K, ef, n_init=100):
     keys, ids, exp = [float(best)], [int(entry)], [False]
     visited = {int(entry)}
     log_d, log_i = [float(best)], [int(entry)]
+    stream = []  # the hand-over log (round 5): ("H", node, evaluated) per hop, then ("C", d, id) of the row's neighbours that could still be admitted
     max_dist, amb, pend, pend_cut, tie = float(best), INF, -INF, False, 0
     sel_ever = False  # a selection tie occurred at all (even one the kernel proves harmless for the beam: the ORDER of the
                       # tied expansions, hence of the log, is then the reference's choice)
@@ -77,6 +78,7 @@ def model_search(X, links, q, K, ef, n_init=100):
                 continue
             visited.add(nb)
             new.append(nb)
+        stream.append(("H", node, len(new)))
         if not new:
             continue
         n_dist += len(new)
@@ -87,6 +89,7 @@ def model_search(X, links, q, K, ef, n_init=100):
         pm = [j for j in range(len(new)) if (d[j] < max_dist if full0 else True)]
         if pend > -INF and full0 and any(x == max_dist for x in d):
             pend_cut = True
+        stream += [("C", d[j], new[j]) for j in pm]
         if pm:
             # the stable merge: beam entries before candidates of equal key, candidates in (key, link order)
             items = [(keys[e], 0, e, ids[e], exp[e]) for e in range(len(keys))] + [(d[j], 1, j, new[j], False) for j in pm]
@@ -111,6 +114,7 @@ def model_search(X, links, q, K, ef, n_init=100):
     cnt = min(nb_, K)
     if not tie and any(k + 1 < nb_ and keys[k] == keys[k + 1] for k in range(cnt)):
         tie = 3
+    model_search.last_stream, model_search.last_entry = stream, int(entry)
     return tie, np.array(keys[:cnt], np.float32), np.array(ids[:cnt], np.int64), log_d, log_i, n_dist, n_hops, sel_ever
 
 
@@ -127,10 +131,26 @@ def test_result_ties_are_decided_by_replaying_the_log(dim, vmax, ef, K):
     want_d, want_l, st = ix.search(Q, K, ef, stats=True)
     by_class = {0: 0, 1: 0, 2: 0, 3: 0}
     replayable = 0
+    resumed, from_log, of_hops = 0, 0, 0
     for qi in range(nq):
         tie, rd, ri, log_d, log_i, n_dist, n_hops, sel_ever = model_search(X, links, Q[qi], K, ef)
         by_class[tie] += 1
         cnt = int(st["count"][qi])
+        # Round 5, the mid-flight hand-over: WHATEVER the flag and wherever the model stopped, the reference's search resumed
+        # from the model's log -- both heaps replayed, stopped at the first hop where the reference would expand another node,
+        # visited set rebuilt from the link rows of the hops taken, then the reference's own loop -- is the oracle's search:
+        # ids, distances, order, counters.  (Queries without a flag as well: the hand-over must be right from any hop.)
+        stream = model_search.last_stream
+        hd = [float(r[2]) if r[0] == "H" else float(r[1]) for r in stream]
+        hi = [int(r[1]) if r[0] == "H" else int(r[2]) for r in stream]
+        hh = [1 if r[0] == "H" else 0 for r in stream]
+        pd, pl, pnd, pnh, rep = ix.replay_search(Q[qi], K, ef, model_search.last_entry, hd, hi, hh)
+        assert np.array_equal(pl, want_l[qi][:cnt]) and np.array_equal(pd, want_d[qi][:cnt]), (qi, tie, "resumed search")
+        assert pnd == int(st["n_dist"][qi]) and pnh == int(st["n_hops"][qi]), (qi, tie, "resumed counters")
+        if tie:
+            resumed += 1
+            from_log += rep
+            of_hops += int(st["n_hops"][qi])
         if tie == 0:  # the model is the reference's search here: ids, distances, counters
             assert np.array_equal(ri, want_l[qi][:cnt]) and np.array_equal(rd, want_d[qi][:cnt]), (qi, tie)
             assert n_dist == int(st["n_dist"][qi]) and n_hops == int(st["n_hops"][qi])
@@ -144,3 +164,5 @@ def test_result_ties_are_decided_by_replaying_the_log(dim, vmax, ef, K):
             assert np.array_equal(pd, want_d[qi][:cnt])
     print("dim=%d values<%d ef=%d: %d queries without a tie flag, %d eviction (a), %d selection (b), %d result-only (d) of which %d replayable"
           % (dim, vmax, ef, by_class[0], by_class[1], by_class[2], by_class[3], replayable))
+    print("   hand-over: %d flagged queries resumed from their logs, all equal to the oracle; %.0f %% of their hops came from the log"
+          % (resumed, 100.0 * from_log / max(of_hops, 1)))

@@ -128,7 +128,7 @@ def apply(spec, undo=False):
 DEFAULTS = dict(visited_factor=27, visited_slots=0, visited_floor=2048, occupancy_target=13, occupancy_roomy=9, cand_factor=2,
                 cand_slots=0, blocks_per_cu=0, sorted_beam=2, sorted_cand_lds=2, sorted_tail_exact_pct=-1, beam_registers=1,
                 sorted_variant=-1, tune_layout=1, shadow_exact=1, entry_kernel=0, visited_tag_bits=0, overflow_list=-1,
-                wide_table_max=-1, query_regs=1)
+                wide_table_max=-1, query_regs=1, tie_replay=1, tie_log_entries=0)
 
 
 def timed(dev, ef, steps):
@@ -166,6 +166,8 @@ for ef in efs:
                     torch.cuda.synchronize()
                     rec = float((ol.long().unsqueeze(2) == gt.unsqueeze(1)).any(dim=2).float().mean().item())
                 r = res.setdefault(spec, dict(ms=[], bytes=byts, geom=g, variant=dev.launch_info()["variant"], recall=rec))
+                if hasattr(dev, "handover_stats"):
+                    r["handover"] = "%s %s" % (dev.replayed_queries(), dev.handover_stats())
                 r["ms"].append(round(ms, 4))
                 if hasattr(dev._lib(), "fnv_debug_phase_cycles"):  # a -DFNV_PHASE_TIMING build: shader cycles per phase
                     L = dev._lib()
@@ -192,6 +194,8 @@ for ef in efs:
               % (ef, spec, r["ms"], NQ / best * 1e3, r["bytes"] / best / 1e9, r["bytes"] / best / 1e9 / 8.0,
                  "-" if r["recall"] is None else "%.4f" % r["recall"], r["geom"]["blocks_per_cu"], r["geom"]["lds_bytes"],
                  r["geom"]["visited_slots"], r["geom"]["cand_slots"], r["geom"]["kernel"], r["variant"]), flush=True)
+        if r.get("handover"):
+            print("      last launch: " + r["handover"], flush=True)
         if r.get("phases"):
             print("      cycles/hop: " + r["phases"], flush=True)
         out.append(dict(ef=ef, set=spec, **{k: v for k, v in r.items()}))

@@ -35,6 +35,7 @@ ap.add_argument("--dtype", default="float32")
 ap.add_argument("--lib", required=True, help="name=path of the -DFNV_TIMELINE build")
 ap.add_argument("--variants", default="-1", help="kernel variants to pin (-1: what the tree's library chose)")
 ap.add_argument("--slices", type=int, default=20)
+ap.add_argument("--opt", action="append", default=[], help="C-ABI option name=value for the timeline build's handle")
 args = ap.parse_args()
 
 cfg = dict(bench.CONFIGS[args.config])
@@ -97,6 +98,9 @@ print("# tree's library: %.4f ms per launch, %d slots (%d per CU), table %d, var
 tl.set_option("tune_layout", 0)
 tl.set_option("visited_slots", int(g["visited_slots"]))
 tl.set_option("sorted_cand_lds", 1 if g["cand_slots"] else 0)
+for o in args.opt:
+    k_, v_ = o.split("=")
+    tl.set_option(k_, int(v_))
 for v in [int(x) for x in args.variants.split(",")]:
     if v < 0:
         v = names.index(chosen) if chosen in names else 1
@@ -130,6 +134,8 @@ for v in [int(x) for x in args.variants.split(",")]:
             print("  %-30s %5d queries, latency p50 %.1f us  p90 %.1f  max %.1f; started %.1f ... %.1f us" %
                   (label, int(sel.sum()), np.percentile(lat[sel], 50), np.percentile(lat[sel], 90), lat[sel].max(), s_us[sel].min(), s_us[sel].max()))
     last = np.argsort(e_us)[-5:]
+    if hasattr(tl, "handover_stats"):
+        print("  hand-overs: %s; by reason %s" % (tl.handover_stats(), tl.replayed_queries()))
     print("  last five to finish: " + ", ".join("%.1f us (%s, started %.1f)" % (e_us[i], ["merged", "twice", "exact"][kind[i]], s_us[i]) for i in last))
     print("| slice (us) | busy slots (mean) | of all | queries finished | rate (M queries/s) |\n|---|---|---|---|---|")
     edges = np.linspace(0, dur, args.slices + 1)
