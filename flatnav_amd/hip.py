@@ -83,8 +83,10 @@ def lib() -> C.CDLL:
     L.fnv_tune.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int]
     L.fnv_last_launch_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.fnv_gather_ceiling.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
-    L.fnv_lane_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-    L.fnv_last_handover_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    # (round-5 entry points: an OLDER build of the library, loaded by the developer A/B tools through FLATNAV_HIP_LIB, lacks them)
+    for name in ("fnv_lane_info", "fnv_last_handover_stats"):
+        if hasattr(L, name) or LIB_PATH == os.path.join(HERE, "libflatnav_hip.so"):
+            getattr(L, name).argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -326,6 +328,8 @@ class DeviceIndex:
         """Hand-overs of the last search (fnv_last_handover_stats): queries resumed from their log, hops taken from the logs,
         hops those queries' merged-beam passes had made, queries searched again from scratch."""
         r = (C.c_uint64 * 4)()
+        if not hasattr(lib(), "fnv_last_handover_stats"):  # (an older build under the A/B tools)
+            return dict(zip(["resumed", "hops_from_log", "hops_of_resumed", "from_scratch"], [0, 0, 0, self.replayed_queries()["total"]]))
         check(lib().fnv_last_handover_stats(self._h, r))
         return dict(zip(["resumed", "hops_from_log", "hops_of_resumed", "from_scratch"], [int(x) for x in r]))
 

@@ -122,7 +122,11 @@ def apply(spec, undo=False):
         return
     for kv in opts.split(","):
         k, v = kv.split("=")
-        d.set_option(k, DEFAULTS[k] if undo else int(v))
+        try:
+            d.set_option(k, DEFAULTS[k] if undo else int(v))
+        except ValueError:  # an option an older build of the library does not know: ignored when undoing
+            if not undo:
+                raise
 
 
 DEFAULTS = dict(visited_factor=27, visited_slots=0, visited_floor=2048, occupancy_target=13, occupancy_roomy=9, cand_factor=2,
