@@ -752,9 +752,12 @@ def run_config(ctx, args, config, main_line):
     if world == 1 and not args.no_secondary:
         view = dev.view()
         view.tune(int(dq[0].data_ptr()), K, EF, 100, nq=NQ)
-        s2 = torch.cuda.Stream()
+        # two streams of their own (round 5: with the process's default stream as one of the two, the main line's launches did
+        # not overlap in two of two runs -- 9.7 M where tools/dev/pipelined_probe.py measures 12.6 M on the same library)
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
         outs2 = (torch.empty((NQ, K), dtype=torch.float32, device=dev_t), torch.empty((NQ, K), dtype=torch.int32, device=dev_t))
-        lanes = [(dev, stream, d_dist, d_lab), (view, s2, outs2[0], outs2[1])]
+        torch.cuda.synchronize()
+        lanes = [(dev, s1, d_dist, d_lab), (view, s2, outs2[0], outs2[1])]
         psteps = max(args.steps, 20) if main_line else max(args.steps, 6)
 
         def pipe_run(n):
