@@ -952,7 +952,7 @@ def recorded_traffic(config, dtype, n, nq, ef):
     separate runs, corrected as MI355X_MICROARCH.md prescribes) -- a RECORDED number, labelled as such; None unless
     the committed passes profiled this very workload."""
     config = config.replace("-uint8", "")  # (the uint8 index is recorded as config c2, dtype uint8)
-    for name in ("r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "pmc_hbm_traffic.json"):
+    for name in ("r5_pmc_hbm_traffic.json", "r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "pmc_hbm_traffic.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):

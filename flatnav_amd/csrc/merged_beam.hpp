@@ -362,11 +362,13 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : R == MB_R ? 3 : waves_per_simd<
           tie = 4;
           return false;
         }
-        if (log_cap != 0u) {  // header, then the candidates that could still be admitted, in link order
+        if (log_cap != 0u) {  // header, then the candidates that could still be admitted, in link order -- ONE store: lane 63
+          // never holds a neighbour (rows of at most 63 links are logged) and writes the header
           const uint32_t cl = (uint32_t)__popcll(pm);
-          if (((pm >> lane) & 1ull) != 0ull)
-            tie_log[log_n + 1u + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = pack(fnv_stl::Entry{d, cand_id});
-          if (lane == 0) tie_log[log_n] = log_header((uint32_t)node, (uint32_t)nn, cl);
+          const bool hdr = lane == WAVE - 1;
+          const uint32_t slot = hdr ? 0u : 1u + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+          const unsigned long long rec = hdr ? log_header((uint32_t)node, (uint32_t)nn, cl) : pack(fnv_stl::Entry{d, cand_id});
+          if (hdr || ((pm >> lane) & 1ull) != 0ull) tie_log[log_n + slot] = rec;
           log_n += 1u + cl;
         }
         if (pm != 0ull) {
