@@ -259,3 +259,29 @@ def test_handover_in_a_full_launch_and_in_small_ones(oracle_mod, hipmod):
                 _assert_exact(tuple(a[:nq] if not isinstance(a, dict) else {k: v[:nq] for k, v in a.items()} for a in want), got,
                               "%s %d queries, shadow %d" % (dt, nq, shadow))
         dev.close()
+
+
+@pytest.mark.parametrize("M", [63, 64, 100])
+def test_handover_log_at_the_row_width_limit(oracle_mod, hipmod, M):
+    # rows of up to 63 links are logged (a hop is at most 64 records, lane 63 writes the header); wider rows write no log and a
+    # tied query is searched again from scratch, as in rounds 2-4 -- the oracle's bytes either way, on data where most queries tie
+    rng = np.random.default_rng(M)
+    X = rng.integers(0, 12, (3000, 24)).astype(np.uint8)
+    Q = rng.integers(0, 12, (400, 24)).astype(np.uint8)
+    ix = oracle_mod.OracleIndex.create("l2", 24, len(X), M, "uint8")
+    ix.add(X, 2 * M)
+    dev = _upload(hipmod, ix)
+    dev.set_option("sorted_beam", 1)
+    dev.set_option("sorted_variant", 1)
+    dev.set_option("shadow_exact", 0)
+    dev.set_option("tie_log_entries", 16384)
+    for K, ef in ((10, 40), (10, 100), (5, 300)):
+        want = ix.search(Q, K, ef, stats=True, threads=8)
+        _assert_exact(want, dev.search(Q, K, ef, stats=True), "M=%d ef=%d" % (M, ef))
+        r, h = dev.replayed_queries(), dev.handover_stats()
+        assert r["total"] > 20 and h["resumed"] + h["from_scratch"] == r["total"], (M, r, h)
+        if M <= 63:
+            assert h["resumed"] > 0.5 * r["total"], (M, r, h)
+        else:
+            assert h["resumed"] == 0, (M, r, h)
+    dev.close()
