@@ -1746,7 +1746,8 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
     // 8-byte bucket at 3 * 2^j slots, two 32-bit tags at 2^j -- so one size up from 3072 slots (4096: same bytes as 6144, a
     // third fewer tags) is a step DOWN in tags per byte and hides the layout that is 18 % faster on 50M x 128 Gaussian rows
     // (6144 slots at 8 queries per CU: 3.06 ms against the rules' 3072 slots at 12 per CU: 3.74 ms; profiles/r5_table_sizes_50m.txt)
-    const uint32_t up2 = base_slots * 2;  // (2^j -> 2^(j+1), 3 * 2^j -> 3 * 2^(j+1): the same tag format as the rules' size)
+    // (only where tags are wide: with 16-bit tags every size has the same format and the neighbours above suffice)
+    const uint32_t up2 = ix->plan.sorted.vis_w != 16u ? base_slots * 2 : 0u;  // 3 * 2^j -> 3 * 2^(j+1): the same tag format
     for (uint32_t slots : {up, down, up2}) {
       if (slots < 256 || slots > (1u << 15)) continue;
       fnv_index_s::LayoutChoice c;
