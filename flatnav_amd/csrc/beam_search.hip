@@ -907,13 +907,14 @@ static int configure_launch(fnv_index_s* ix, SearchParams& p, kernel_fn kern, in
       }
     }
   }
-  // The GRID stays what the occupancy API counts (rounds 1-3), also where that is more than a CU really keeps resident: the
-  // surplus workgroups start when the first slots exit, find the dispenser empty and leave.  Sizing the grid by
-  // `really_resident` was measured (r4_run26 / r4_run28, alternating with this form on one copy of each index) and lost
-  // 0.7-2.9 % wherever the two differ (10M x 768 ef=670: 99.2 vs 96.5 ms; 1M x 128 ef=100: 1.887 vs 1.864): the exact tail
-  // is a percentage of the grid, and 75 % of the API's count (82 % of the resident slots) happens to sit nearer the best
-  // tail length than 75 % or 100 % of the resident slots do.  (profiles/r4_launch_timeline.md)
-  int bpc = resident(lds_bytes);
+  // The GRID is the slots a CU really keeps resident (round 5).  Rounds 1-4 launched the occupancy API's count, also where
+  // that is one more than the LDS granules allow (the surplus workgroup starts when the first slot exits, finds the dispenser
+  // empty and leaves): sizing the grid by `really_resident` lost 0.7-2.9 % then, because the exact tail is a percentage of the
+  // grid and 75 % of the API's count sat nearer the best tail length.  With the hand-over the configurations where the two
+  // counts differ run without a tail, and the two grids measure the same (c4 ef=110: 2.0857 vs 2.0837 ms, 10M x 768 ef=670:
+  // 102.37 vs 102.40 ms; gpurun r5 run 24) -- so `blocks_per_cu` now says what it means.  The table-size rules above keep
+  // comparing the API's counts (the layouts they choose are the measured ones).
+  int bpc = really_resident(lds_bytes);
   if (bpc < 1) bpc = 1;
   if (ix->blocks_per_cu > 0) bpc = std::min<int>(bpc, (int)ix->blocks_per_cu);
   *lds_out = lds_bytes;

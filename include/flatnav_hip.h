@@ -287,9 +287,9 @@ int fnv_last_replayed_queries(fnv_index_t index, uint64_t out[5]);
  * blocks_per_cu, visited_slots, cand_slots (LDS entries of the exact search's candidates heap), kernel: 0 = two-heap
  * kernel, 1 = merged-beam kernel with the beam in registers, 2 = with the beam in LDS, tail_exact: the last that-many queries of the launch
  * went straight to the exact search (merged-beam kernel, see the "sorted_tail_exact_pct" option)}.
- * blocks_per_cu is the grid's share per CU as the HIP occupancy API counts it; gfx950 hands LDS out in 1280-byte granules, so a CU
- * keeps min(blocks_per_cu, 163840 / (ceil(lds_bytes / 1280) * 1280)) of them resident at a time (the surplus workgroups start when
- * the first slots exit and find no query left). */
+ * blocks_per_cu = the query slots a CU keeps resident = the grid's share per CU (round 5; gfx950 hands LDS out in 1280-byte
+ * granules, so this is min(what the HIP occupancy API counts, 163840 / (ceil(lds_bytes / 1280) * 1280)); rounds 1-4 launched the
+ * API's count). */
 int fnv_last_launch_geometry(fnv_index_t index, uint64_t geom[8]);
 
 /* The adaptive kernel choice ("sorted_beam" = 2) measures its variants on the caller's launches: up to 18 launches per
