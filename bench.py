@@ -713,8 +713,8 @@ def run_config(ctx, args, config, main_line):
                           d_cnt.data_ptr(), d_nd.data_ptr(), d_nh.data_ptr(), stream=stream.cuda_stream)  # (geometry of a timed launch)
         torch.cuda.synchronize()
         geom = dev.launch_geometry()
-        # blocks_per_cu is the grid's share per CU (the occupancy API's count); gfx950 hands LDS out in 1280-byte granules
-        # (tools/dev/probes/lds_granule.cpp), so an LDS-bound layout keeps fewer of them resident at a time:
+        # blocks_per_cu = the grid's share per CU = (since round 5) the slots a CU really keeps resident: gfx950 hands LDS out in
+        # 1280-byte granules (tools/dev/probes/lds_granule.cpp); rounds 1-4 launched the occupancy API's count, which can be one more
         geom["resident_per_cu"] = resident_per_cu(geom["blocks_per_cu"], geom["lds_bytes"])
         info = dev.launch_info()
         replay = dev.replayed_queries()
