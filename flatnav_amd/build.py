@@ -24,7 +24,8 @@ MAIN = os.path.join(CSRC, "beam_search.hip")
 INST = os.path.join(CSRC, "kernel_inst.hip")
 TYPES = [("float", "f32"), ("uint8_t", "u8"), ("int8_t", "i8")]
 METRICS = [(0, "l2"), (1, "ip")]
-FAMILIES = [(0, "exact"), (3, "wire"), (4, "merged"), (5, "merged1"), (6, "merged0"), (7, "merged2")]
+FAMILIES = [(0, "exact"), (3, "wire"), (4, "merged"), (5, "merged1"), (6, "merged0"), (7, "merged2"),
+            (8, "merged_d"), (9, "merged1_d"), (10, "merged0_d"), (11, "merged2_d")]  # 8-11: the DIRECT forms (small launches)
 
 
 def hipcc() -> str:

@@ -138,6 +138,10 @@ const KernelTable& kernel_table(int, int) {
         k.merged1[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_DEV_METRIC, FNV_DEV_G, FNV_DEV_CU, true, 1>;
         k.merged0[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_DEV_METRIC, FNV_DEV_G, FNV_DEV_CU, true, 0>;
         k.merged2[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_DEV_METRIC, FNV_DEV_G, FNV_DEV_CU, true, 2>;
+        k.merged_d[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_DEV_METRIC, FNV_DEV_G, FNV_DEV_CU, true, MB_R, true>;
+        k.merged1_d[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_DEV_METRIC, FNV_DEV_G, FNV_DEV_CU, true, 1, true>;
+        k.merged0_d[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_DEV_METRIC, FNV_DEV_G, FNV_DEV_CU, true, 0, true>;
+        k.merged2_d[c][f] = beam_search_merged_kernel<FNV_DEV_T, FNV_DEV_METRIC, FNV_DEV_G, FNV_DEV_CU, true, 2, true>;
         k.select[c][f] = wire_select_kernel<FNV_DEV_T, FNV_DEV_METRIC, FNV_DEV_G, FNV_DEV_CU, true>;
         k.connect[c][f] = wire_connect_kernel<FNV_DEV_T, FNV_DEV_METRIC, FNV_DEV_G, FNV_DEV_CU, true>;
       }
@@ -158,6 +162,10 @@ const KernelTable& kernel_table(int dtype, int metric) {
     fill_merged1_##tag##_##mtag(tables[i]);     \
     fill_merged0_##tag##_##mtag(tables[i]);     \
     fill_merged2_##tag##_##mtag(tables[i]);     \
+    fill_merged_d_##tag##_##mtag(tables[i]);    \
+    fill_merged1_d_##tag##_##mtag(tables[i]);   \
+    fill_merged0_d_##tag##_##mtag(tables[i]);   \
+    fill_merged2_d_##tag##_##mtag(tables[i]);   \
     fill_wire_##tag##_##mtag(tables[i]);        \
     i++;
     FNV_FOR_EACH_TYPE_METRIC(FNV_FILL)
@@ -170,8 +178,9 @@ const KernelTable& kernel_table(int dtype, int metric) {
 
 kernel_fn pick_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).exact[cfg][full]; }
 kernel_fn pick_scan_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).scan[cfg][full]; }
-kernel_fn pick_sorted_kernel(int dtype, int metric, int cfg, bool full, bool lds, int B) {
+kernel_fn pick_sorted_kernel(int dtype, int metric, int cfg, bool full, bool lds, int B, bool direct = false) {
   const KernelTable& t = kernel_table(dtype, metric);
+  if (direct) return lds ? t.merged0_d[cfg][full] : B <= WAVE ? t.merged1_d[cfg][full] : B <= 2 * WAVE ? t.merged2_d[cfg][full] : t.merged_d[cfg][full];
   return lds ? t.merged0[cfg][full] : B <= WAVE ? t.merged1[cfg][full] : B <= 2 * WAVE ? t.merged2[cfg][full] : t.merged[cfg][full];
 }
 wire_fn pick_wire_kernel(int dtype, int metric, int cfg, bool full) { return kernel_table(dtype, metric).select[cfg][full]; }
@@ -187,6 +196,7 @@ struct LaunchPlan {
   bool full = false;
   uint64_t capacity = 0, options_version = 0;
   kernel_fn kern = nullptr, skern = nullptr;  // exact two-heap kernel; merged-beam kernel (mode != 0)
+  kernel_fn skern_direct = nullptr;           // ... its DIRECT form (small launches on small indexes)
   SearchParams heaps, sorted;                 // geometry + LDS layout for each (per-call fields unset)
   uint32_t lds = 0, slds = 0;
   int bpc = 0, sbpc = 0;
@@ -212,7 +222,7 @@ struct IndexOptions {
           cand_slots = 0, spill_entries = 16384, blocks_per_cu = 0, visited_wide = 0,
           entry_kernel = 0, output_node_ids = 0, visited_tag_bits = 0, sorted_beam = 2,
           sorted_beam_min = 1, sorted_cand_lds = 2, sorted_tail_exact_pct = -1, beam_registers = 1,
-          sorted_variant = -1, tune_layout = 1, shadow_exact = 1, tie_replay = 1, tie_log_entries = 0;
+          sorted_variant = -1, tune_layout = 1, shadow_exact = 1, tie_replay = 1, tie_log_entries = 0, visited_direct = 1;
   int64_t overflow_list = -1;  // -1: automatic (a list in HBM only when the bitmap is larger than 512 KB)
 };
 
@@ -719,11 +729,12 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   else if (n == "shadow_exact") ix->shadow_exact = value;
   else if (n == "tie_replay") ix->tie_replay = value;
   else if (n == "tie_log_entries") ix->tie_log_entries = value;
+  else if (n == "visited_direct") ix->visited_direct = value;  // (read per launch)
   else return fail(FNV_ERR_INVALID, "unknown option: " + n);
   // What fnv_tune measured (kernel variant, LDS layout) stays valid across options that change neither the launch plan
   // nor the kernel choice: Index.h::addBatchDevice flips output_node_ids around every device build, and a tune costs
   // dozens of launches.  (output_node_ids is read per launch; shadow_exact per launch; tune_layout by fnv_tune itself.)
-  const bool keeps_tuning = n == "output_node_ids" || n == "shadow_exact" || n == "tune_layout";
+  const bool keeps_tuning = n == "output_node_ids" || n == "shadow_exact" || n == "tune_layout" || n == "visited_direct";
   if (!keeps_tuning) {
     ix->options_version++;
     ix->tuner.clear();
@@ -1041,6 +1052,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     plan.mode = (!tagged || !want) ? MODE_HEAPS : (B <= MB_MAX_BEAM && ix->beam_registers != 0) ? MODE_MERGED_REGS : MODE_MERGED_LDS;
     if (plan.mode != MODE_HEAPS) {
       plan.skern = pick_sorted_kernel(ix->dtype, ix->metric, cfg, full, plan.mode == MODE_MERGED_LDS, B);
+      plan.skern_direct = pick_sorted_kernel(ix->dtype, ix->metric, cfg, full, plan.mode == MODE_MERGED_LDS, B, true);
       // a layout that fnv_tune measured for this beam width overrides the rules below (heap home, table size)
       fnv_index_s::LayoutChoice lc;
       if (auto it = ix->layouts.find(B); it != ix->layouts.end()) lc = it->second;
@@ -1159,7 +1171,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     }
   }
   const int bpc = sorted ? plan.sbpc : plan.bpc;
-  const uint32_t lds_bytes = sorted ? plan.slds : plan.lds;
+  uint32_t lds_bytes = sorted ? plan.slds : plan.lds;
   // Shadow mode (search_params.h): a launch that fills at most a quarter of the resident slots starts, next to the
   // merged-beam search of every query, an exact search of the same query on another slot.  A query in which equal keys
   // meet at a decision is then answered after ONE exact-search latency from the start of the launch instead of a
@@ -1189,6 +1201,36 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   if (rc) return rc;
 
   SearchParams p = sorted ? plan.sorted : plan.heaps;
+  // Small launches on small indexes (round 5): when a bitmap of ALL node ids fits the LDS of the slots the launch needs, the
+  // visited set is that bitmap (csrc/visited.hpp visited_insert_direct: one LDS round trip per link row, nothing overflows)
+  // instead of the tag table, and the launch runs the kernel's DIRECT instantiation -- a launch that leaves the GPU mostly idle is a chain of dependent latencies, and the tag table
+  // is 1.8 k of a lone hop's 7.9 k cycles.  The table is the last but two of the slot's LDS areas: only what follows it moves.
+  // Only in launches that fill at most a quarter of the slots, and not when the caller has pinned the table's shape
+  // ("visited_slots", "visited_tag_bits", "visited_wide"); "visited_direct" = 0 turns it off.
+  const bool small_launch = 4 * nq <= (uint64_t)bpc * (uint64_t)ix->num_cus;  // (the condition of shadow mode)
+  bool direct = false;
+  if (sorted && small_launch && ix->visited_direct != 0 && ix->visited_slots == 0 && ix->visited_tag_bits == 0 && ix->visited_wide == 0 && p.vis_tag16) {
+    const uint64_t ids = std::max<uint64_t>(ix->capacity, ix->parent ? ix->parent->capacity : 0);
+    const uint64_t bytes = ((ids + 7) / 8 + 15) / 16 * 16;
+    auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+    if (bytes + p.off_vis + 1024 <= kLdsPerCu) {
+      SearchParams d = p;
+      d.vis_w = 1;
+      d.vis_bytes = (uint32_t)bytes;
+      d.vis_slots = (uint32_t)(bytes * 8);  // (what fnv_last_launch_geometry reports: one slot per node id)
+      uint32_t off = align16(d.off_vis + d.vis_bytes);
+      d.off_stage_ids = off;
+      off = align16(off + (WAVE + 1) * 4);
+      d.off_ovf = off;
+      off = align16(off + (OVF_LIST + 2 + STASH) * 4);
+      const uint64_t per_cu = std::min<uint64_t>((uint64_t)bpc, kLdsPerCu / lds_allocated(off));
+      if (off <= kLdsPerCu && (uint64_t)nslots <= per_cu * (uint64_t)ix->num_cus) {
+        p = d;
+        lds_bytes = off;
+        direct = true;
+      }
+    }
+  }
   p.labels = node_ids ? nullptr : ix->d_labels;
   p.queries = (const uint8_t*)d_queries;
   p.out_dist = d_out_dist;
@@ -1248,7 +1290,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     p.nq = (uint32_t)(2 * nq);
     p.tail_exact = 0u;
   }
-  kernel_fn kern = sorted ? plan.skern : plan.kern;
+  kernel_fn kern = !sorted ? plan.kern : direct ? plan.skern_direct : plan.skern;
   HIP_TRY(raise_lds_limit((const void*)kern, ix->device, lds_bytes));
   hipLaunchKernelGGL(kern, dim3(nslots), dim3(WAVE), lds_bytes, stream, p);
   HIP_TRY(hipGetLastError());

@@ -1,7 +1,9 @@
 // kernel_inst.hip -- one compilation = the instantiations of ONE kernel family for ONE (element type, metric):
 //   hipcc -c -DFNV_INST_T=float -DFNV_INST_TAG=f32 -DFNV_INST_METRIC=0 -DFNV_INST_MTAG=l2 -DFNV_INST_FAMILY=4 ...
 // families: 0 exact two-heap kernel + entry scan, 3 wiring kernels, 4 merged beam (<= 256 entries in registers),
-// 5 merged beam (<= 64 entries in registers), 6 merged beam (LDS, any width), 7 merged beam (<= 128 in registers).  flatnav_amd/build.py compiles the 36 combinations in parallel and links them with beam_search.hip.
+// 5 merged beam (<= 64 entries in registers), 6 merged beam (LDS, any width), 7 merged beam (<= 128 in registers), 8-11 the
+// DIRECT forms of 4-7 (small launches on small indexes: the visited set is a bitmap in LDS).  flatnav_amd/build.py compiles the
+// 60 combinations in parallel and links them with beam_search.hip.
 #include <hip/hip_runtime.h>
 
 #include "kernel_table.h"
@@ -45,6 +47,18 @@ static void fill_rows(KernelTable& t) {
 #elif FNV_INST_FAMILY == 7
 #define FNV_COMMA_TWO , 2
   FNV_ROW(t.merged2, beam_search_merged_kernel, FNV_COMMA_TWO)
+#elif FNV_INST_FAMILY == 8
+#define FNV_COMMA_MB_R_D , MB_R, true
+  FNV_ROW(t.merged_d, beam_search_merged_kernel, FNV_COMMA_MB_R_D)
+#elif FNV_INST_FAMILY == 9
+#define FNV_COMMA_ONE_D , 1, true
+  FNV_ROW(t.merged1_d, beam_search_merged_kernel, FNV_COMMA_ONE_D)
+#elif FNV_INST_FAMILY == 10
+#define FNV_COMMA_ZERO_D , 0, true
+  FNV_ROW(t.merged0_d, beam_search_merged_kernel, FNV_COMMA_ZERO_D)
+#elif FNV_INST_FAMILY == 11
+#define FNV_COMMA_TWO_D , 2, true
+  FNV_ROW(t.merged2_d, beam_search_merged_kernel, FNV_COMMA_TWO_D)
 #else
   FNV_ROW(t.select, wire_select_kernel)
   FNV_ROW(t.connect, wire_connect_kernel)
@@ -61,6 +75,14 @@ void FNV_CAT(fill_merged1_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 void FNV_CAT(fill_merged0_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 #elif FNV_INST_FAMILY == 7
 void FNV_CAT(fill_merged2_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
+#elif FNV_INST_FAMILY == 8
+void FNV_CAT(fill_merged_d_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
+#elif FNV_INST_FAMILY == 9
+void FNV_CAT(fill_merged1_d_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
+#elif FNV_INST_FAMILY == 10
+void FNV_CAT(fill_merged0_d_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
+#elif FNV_INST_FAMILY == 11
+void FNV_CAT(fill_merged2_d_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 #else
 void FNV_CAT(fill_wire_, FNV_INST_TAG, _, FNV_INST_MTAG, )(KernelTable& t) {
 #endif

@@ -38,6 +38,7 @@ struct KernelTable {
   kernel_fn merged1[kNumCfgs][2];      // ... its one-chunk form (beam <= 64)
   kernel_fn merged0[kNumCfgs][2];      // ... its LDS form (any beam width)
   kernel_fn merged2[kNumCfgs][2];      // ... its two-chunk form (beam <= 128)
+  kernel_fn merged_d[kNumCfgs][2], merged1_d[kNumCfgs][2], merged0_d[kNumCfgs][2], merged2_d[kNumCfgs][2];  // their DIRECT forms
   wire_fn select[kNumCfgs][2];         // wire_select_kernel
   wire_fn connect[kNumCfgs][2];        // wire_connect_kernel
 };
@@ -53,6 +54,10 @@ struct KernelTable {
   void fill_merged1_##tag##_##mtag(KernelTable& t);      \
   void fill_merged0_##tag##_##mtag(KernelTable& t);      \
   void fill_merged2_##tag##_##mtag(KernelTable& t);      \
+  void fill_merged_d_##tag##_##mtag(KernelTable& t);     \
+  void fill_merged1_d_##tag##_##mtag(KernelTable& t);    \
+  void fill_merged0_d_##tag##_##mtag(KernelTable& t);    \
+  void fill_merged2_d_##tag##_##mtag(KernelTable& t);    \
   void fill_wire_##tag##_##mtag(KernelTable& t);
 FNV_FOR_EACH_TYPE_METRIC(FNV_DECLARE_FILLERS)
 #undef FNV_DECLARE_FILLERS

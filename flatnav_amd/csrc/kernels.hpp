@@ -331,7 +331,7 @@ struct ExactResume {
 // `resumed` (false: a search from scratch): heaps, visited set and counters come from a replayed log (`rs`); the search starts
 // at the loop head.  (A run-time flag, not a template parameter: the merged-beam kernel inlines this function ONCE for both;
 // `rs` by value: a pointer to it would keep the struct in scratch memory.)
-template <typename T, int METRIC, int G, int CU, bool FULL>
+template <typename T, int METRIC, int G, int CU, bool FULL, bool DIRECT = false>
 __device__ __forceinline__ void exact_query(const ExactCtx& x, const Query<G, CU>& q, int qi, uint32_t entry, float best_d, int lane,
                                             PhaseTimer& ph, const uint32_t* stop = nullptr, bool resumed = false,
                                             ExactResume rs = ExactResume{ExactState{1, 1, 0.f, ST_OK}, 0u, 0u, false}) {
@@ -372,10 +372,8 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, const Query<G, CU
     }
     if (!tagged) {
       if (lane == 0) visited_insert_lds(vis, cold_args()->vis_slots - 1, cold_args()->vis_shift, entry);
-    } else if (vg.w == 16) {
-      visited_insert_tag16(vis, vg, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
     } else {
-      visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), vg, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
+      visited_insert<DIRECT>(vis, vg, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
     }
   }
   // (ovf is wave-uniform: the visited inserts set it for every lane)
@@ -409,8 +407,7 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, const Query<G, CU
       PH_MARK(3);
       bool isnew = false;
       if (tagged) {
-        if (vg.w == 16) isnew = visited_insert_tag16(vis, vg, act, id, bitmap, ovf_list, ovf_glist, ovf);
-        else isnew = visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), vg, act, id, bitmap, ovf_list, ovf_glist, ovf);
+        isnew = visited_insert<DIRECT>(vis, vg, act, id, bitmap, ovf_list, ovf_glist, ovf);
       } else {  // 32-bit open addressing ("visited_wide", tests): hands over to the bitmap at 3/4 load
         const uint32_t vis_mask = cold_args()->vis_slots - 1, vis_shift = cold_args()->vis_shift;
         if (!ovf && vis_count + WAVE > cold_args()->vis_limit) ovf = true;
@@ -571,6 +568,7 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, const Query<G, CU
 // state from which exact_query<..., RESUME> continues.  `ovf`: whether the merged-beam pass sent ids to the HBM bitmap.  The
 // visited set is left as the merged-beam pass had it when every logged hop was the reference's; else it is rebuilt for the
 // hops that were.  Returns the number of hops taken from the log.
+template <bool DIRECT>
 __device__ __forceinline__ uint32_t replay_log(const ExactCtx& x, const unsigned long long* log, uint32_t records, uint32_t entry,
                                                float best_d, bool ovf, int lane, PhaseTimer& ph, ExactResume& out) {
   asm volatile("" : "+v"(lane));
@@ -631,8 +629,7 @@ __device__ __forceinline__ uint32_t replay_log(const ExactCtx& x, const unsigned
     ovf = false;
     const VisGeom vg = x.vg;
     auto insert = [&](bool act, uint32_t id) {
-      if (vg.w == 16) visited_insert_tag16(vis, vg, act, id, bitmap, ovf_list, ovf_glist, ovf);
-      else visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), vg, act, id, bitmap, ovf_list, ovf_glist, ovf);
+      visited_insert<DIRECT>(vis, vg, act, id, bitmap, ovf_list, ovf_glist, ovf);
     };
     insert(lane == 0, entry);
     if (hops > 0) {

@@ -108,7 +108,9 @@ __device__ __forceinline__ float lane_of(const float (&a)[R], int r, int l) {
   return __int_as_float(s);
 }
 
-template <typename T, int METRIC, int G, int CU, bool FULL, int R>
+// DIRECT (round 5): the instantiations that small launches on small indexes run -- the visited set is a bitmap of all node ids
+// in LDS (visited.hpp visited_insert_direct; search_params.h vis_w == 1), the tag-table code is compiled out.
+template <typename T, int METRIC, int G, int CU, bool FULL, int R, bool DIRECT = false>
 __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : R == MB_R ? 3 : waves_per_simd<G>(FNV_SORTED_WAVES_PER_SIMD)) void beam_search_merged_kernel(const SearchParams p) {
   // (128-byte rows: 97 registers as compiled for four waves per SIMD -- one over the budget of five, which they fit.
   //  The four-chunk form -- beams of 129-256 entries -- is compiled for THREE waves per SIMD (168 registers, round 4): its
@@ -189,8 +191,7 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : R == MB_R ? 3 : waves_per_simd<
     int n = 1;
     float max_dist = best_d;
     bool ovf = false;
-    if (vg.w == 16) visited_insert_tag16(vis, vg, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
-    else visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), vg, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
+    visited_insert<DIRECT>(vis, vg, lane == 0, entry, bitmap, ovf_list, ovf_glist, ovf);
     int tie = best_d != best_d ? 4 : 0;
     if ((uint32_t)item + ca->tail_exact >= ca->nq) tie = 5;  // last round of the launch: straight to the exact search
     if (shadow) tie = 5;
@@ -305,8 +306,7 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : R == MB_R ? 3 : waves_per_simd<
       auto row_chunk = [&](const int m0, const uint32_t id) -> bool {
         const bool act = m0 + lane < M;
         bool isnew;
-        if (vg.w == 16) isnew = visited_insert_tag16(vis, vg, act, id, bitmap, ovf_list, ovf_glist, ovf);
-        else isnew = visited_insert_tagw(reinterpret_cast<unsigned long long*>(vis), vg, act, id, bitmap, ovf_list, ovf_glist, ovf);
+        isnew = visited_insert<DIRECT>(vis, vg, act, id, bitmap, ovf_list, ovf_glist, ovf);
         // the guess is requested HERE: after the node's own row has been consumed (the wait for that row is a wait for
         // every request in flight, so a guess issued earlier would be waited for as well) and ahead of the gathers
         if (m0 == 0) guess_next(node, runner_up);
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : R == MB_R ? 3 : waves_per_simd<
       ExactResume rs{ExactState{1, 1, 0.f, ST_OK}, 0u, 0u, false};
       if (resume) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the log's stores have left this wave (the reader loads past the L1)
-        const uint32_t taken = replay_log(x, xa->tie_log + (uint64_t)blockIdx.x * xa->log_entries, log_n, entry, best_d, ovf, lane, ph, rs);
+        const uint32_t taken = replay_log<DIRECT>(x, xa->tie_log + (uint64_t)blockIdx.x * xa->log_entries, log_n, entry, best_d, ovf, lane, ph, rs);
         if (lane == 0) {  // [5] queries resumed from their log, [6] hops taken from the logs, [7] hops the merged-beam passes had made
           uint32_t* rc = xa->redo_count;
           atomicAdd(rc + 5, 1u);
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : R == MB_R ? 3 : waves_per_simd<
           atomicAdd(rc + 7, n_hops);
         }
       }
-      exact_query<T, METRIC, G, CU, FULL>(x, q, qi, entry, best_d, lane, ph, shadow ? xa->done_flags + qi : nullptr, resume, rs);
+      exact_query<T, METRIC, G, CU, FULL, DIRECT>(x, q, qi, entry, best_d, lane, ph, shadow ? xa->done_flags + qi : nullptr, resume, rs);
 #ifdef FNV_TIMELINE  // bits 60-61 of the end reading: 1 = searched twice (equal keys), 2 = sent straight to the exact search
       if (lane == 0 && !shadow && xa->out_ndist && xa->out_nhops) {
         xa->out_ndist[qi] = tl_start;

@@ -93,7 +93,8 @@ struct SearchParams {
   uint32_t n_scan, scan_step;
   uint32_t vis_slots, vis_shift, vis_limit;
   uint32_t vis_tag16;      // 1: bucketed tag table (below; tag width vis_w), 0: 32-bit open addressing
-  uint32_t vis_w;          // 16: four tags per 8-byte bucket; 21 / 32: three / two tags per 64-bit bucket
+  uint32_t vis_w;          // 16: four tags per 8-byte bucket; 21 / 32: three / two tags per 64-bit bucket;
+                           // 1 (round 5, small launches on small indexes): no table -- a bitmap of all node ids, vis_bytes long
   uint32_t vis_bytes;      // LDS bytes of the table
   uint32_t vis_nmask, vis_rshift, vis_rmask;  // tag16: 2^nbits-1, t = nbits-k, 2^t-1
   uint32_t vis_mult;       // tag16: buckets = vis_mult * 2^k with vis_mult in {1, 3}

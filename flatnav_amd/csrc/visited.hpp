@@ -247,4 +247,26 @@ __device__ __forceinline__ bool visited_insert_tagw(unsigned long long* tab, con
   return isnew != 0u;
 }
 
+// Round 5, small launches on small indexes (search_params.h, vis_w == 1): the visited set is a plain bitmap of ALL node ids in
+// LDS -- one atomic OR with return per id: a single LDS round trip, nothing to overflow, no stash, no HBM bitmap.  (A lone wave
+// spends 1.8 k of its hop's 7.9 k cycles in the tag table: profiles/r5_phase_cycles_c2.txt.)
+__device__ __forceinline__ bool visited_insert_direct(uint32_t* tab, bool act, uint32_t id) {
+  uint32_t old = ~0u;
+  if (act) old = atomicOr(tab + (id >> 5), 1u << (id & 31u));
+  return ((old >> (id & 31u)) & 1u) == 0u;
+}
+
+// The visited set of the slot.  DIRECT is a property of the KERNEL (its own instantiations, launched for small launches only):
+// a run-time third form next to the two tag tables cost the loaded hop of the bench shapes 1-4 % (code layout; r5_run32).
+template <bool DIRECT>
+__device__ __forceinline__ bool visited_insert(uint32_t* tab, const VisGeom& g, bool act, uint32_t id, uint32_t* bitmap,
+                                               uint32_t* ovf_list, uint32_t* ovf_glist, bool& used_bitmap) {
+  if constexpr (DIRECT) {
+    return visited_insert_direct(tab, act, id);
+  } else {
+    if (g.w == 16) return visited_insert_tag16(tab, g, act, id, bitmap, ovf_list, ovf_glist, used_bitmap);
+    return visited_insert_tagw(reinterpret_cast<unsigned long long*>(tab), g, act, id, bitmap, ovf_list, ovf_glist, used_bitmap);
+  }
+}
+
 }  // namespace fnv_dev

@@ -199,6 +199,10 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *                     (fnv_last_handover_stats) instead of being searched again from scratch; 0 = from scratch, as in
  *                     rounds 2-4.  "tie_log_entries": 8-byte log records per resident query slot in HBM (0 = automatic:
  *                     24 per beam entry + 512, in [1024, 16384]).  Same bytes.
+ *   "visited_direct"  1 (default): a launch that fills at most a quarter of the resident query slots keeps its visited set as a
+ *                     plain bitmap of ALL node ids in LDS whenever that fits the slots it needs (up to ~1.2 M nodes at one
+ *                     query per CU): one LDS round trip per link row, nothing overflows.  0 = the tag table always; also off
+ *                     while "visited_slots", "visited_tag_bits" or "visited_wide" pin the table's shape.  Same bytes.
  *   "tune_layout"     1 (default): fnv_tune also measures the LDS layout (see fnv_tune); 0 = kernel variants only
  *   "sorted_beam_min" smallest beam width the merged-beam kernel is used for (default 1)
  *   "sorted_cand_lds" where the exact re-run of the merged-beam kernel keeps its candidates heap: 2 (default) = in LDS

@@ -285,3 +285,42 @@ def test_handover_log_at_the_row_width_limit(oracle_mod, hipmod, M):
         else:
             assert h["resumed"] == 0, (M, r, h)
     dev.close()
+
+
+def test_small_launches_keep_the_visited_set_as_an_lds_bitmap(oracle_mod, hipmod):
+    # Round 5: a launch that fills at most a quarter of the slots keeps its visited set as a plain bitmap of all node ids in LDS
+    # when that fits (csrc/visited.hpp visited_insert_direct) -- one LDS round trip per link row, nothing overflows -- for the
+    # merged-beam pass, its exact shadows, hand-overs (a rewind rebuilds the bitmap) and straight exact searches alike.  The
+    # oracle's bytes with it and without it ("visited_direct" = 0), on tie-free, tie-heavy and every-query-ties data.
+    rng = np.random.default_rng(11)
+    X, Q = ds.sift_like(20000, 600)
+    cases = [("sift_f32", X, Q, "l2", "float32", 32),
+             ("u8_ties", rng.integers(0, 16, (8000, 32)).astype(np.uint8), rng.integers(0, 16, (600, 32)).astype(np.uint8), "l2", "uint8", 16),
+             ("u8_dense_ties", rng.integers(0, 4, (8000, 16)).astype(np.uint8), rng.integers(0, 4, (600, 16)).astype(np.uint8), "l2", "uint8", 16),
+             ("i8_ip", rng.integers(-20, 20, (6000, 40)).astype(np.int8), rng.integers(-20, 20, (600, 40)).astype(np.int8), "ip", "int8", 16)]
+    for name, XX, QQ, metric, dt, M in cases:
+        ix = oracle_mod.OracleIndex.create(metric, XX.shape[1], len(XX), M, dt)
+        ix.add(XX, 48)
+        dev = _upload(hipmod, ix)
+        for K, ef in ((10, 52), (10, 200), (1, 8), (64, 64), (30, 700)):
+            want = ix.search(QQ, K, ef, stats=True, threads=8)
+            for shadow in (1, 0):
+                dev.set_option("shadow_exact", shadow)
+                for nq in (1, 7, 64, 300, 600):
+                    w = tuple(a[:nq] if not isinstance(a, dict) else {k: v[:nq] for k, v in a.items()} for a in want)
+                    lds = {}
+                    for direct in (1, 0):
+                        dev.set_option("visited_direct", direct)
+                        _assert_exact(w, dev.search(QQ[:nq], K, ef, stats=True), "%s K=%d ef=%d %d queries shadow %d direct %d" % (name, K, ef, nq, shadow, direct))
+                        g = dev.launch_geometry()
+                        lds[direct] = (g["lds_bytes"], g["visited_slots"])
+                    # the bitmap is one bit per node id (rounded up to 16 bytes), whatever the beam width
+                    bits = (len(XX) + 127) // 128 * 128
+                    assert lds[0][1] != bits and (lds[1][1] == bits or nq > 64), (name, nq, lds)
+        # a pinned table shape wins over the bitmap (the tests that force the table into stash and HBM bitmap keep doing so)
+        dev.set_option("visited_direct", 1)
+        dev.set_option("visited_slots", 256)
+        want = ix.search(QQ[:64], 10, 100, stats=True, threads=8)
+        _assert_exact(want, dev.search(QQ[:64], 10, 100, stats=True), name + " pinned table")
+        assert dev.launch_geometry()["visited_slots"] == 256
+        dev.close()
