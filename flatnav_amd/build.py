@@ -1,8 +1,8 @@
 """Builds the in-tree gfx950 shared library (C ABI of include/flatnav_hip.h) with hipcc.
 
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the dev container as well as on the MI355X box.
-The kernels are templates over <element type, metric, row configuration>; their instantiations are compiled as 36
-objects (kernel_inst.hip: 6 kernel families x 3 element types x 2 metrics) in parallel, plus beam_search.hip (host
+The kernels are templates over <element type, metric, row configuration>; their instantiations are compiled as 60
+objects (kernel_inst.hip: 10 kernel families x 3 element types x 2 metrics) in parallel, plus beam_search.hip (host
 code, C ABI, re-layout kernels), and linked into libflatnav_hip.so.  Objects are cached in csrc/_obj and rebuilt
 when a source they include is newer.  The .so stays in-tree (git-ignored, but shipped by gpurun)."""
 from __future__ import annotations
