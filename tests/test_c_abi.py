@@ -28,6 +28,17 @@ def test_header_and_binding_agree():
     assert _declared_symbols() == sorted(hip.C_ABI_SYMBOLS)
 
 
+def test_every_option_the_library_accepts_is_documented_in_the_header():
+    # fnv_set_option's names (csrc/beam_search.hip) against the option list of include/flatnav_hip.h
+    src = open(os.path.join(ROOT, "flatnav_amd", "csrc", "beam_search.hip")).read()
+    body = src[src.index("int fnv_set_option("):]
+    body = body[:body.index("\nint ", 10)]
+    names = sorted(set(re.findall(r'n == "([a-z_0-9]+)"', body)))
+    assert len(names) >= 25, names
+    hdr = open(os.path.join(ROOT, "include", "flatnav_hip.h")).read()
+    assert [n for n in names if '"%s"' % n not in hdr] == []
+
+
 def test_library_exports_every_declared_symbol(libpath):
     lib = C.CDLL(libpath)
     for name in _declared_symbols():
