@@ -374,6 +374,9 @@ def contract_line(out, names, main_name, full_path):
                              for k, v in (out.get("timed_regions") or {}).items() if k != "note"} or None
     if out.get("pipelined"):
         line["two_launches_in_flight"] = _sig(out["pipelined"]["value"])
+    if out.get("single_query"):
+        line["single_query_ms"] = {"ef": out["single_query"]["ef_search"], "wall_p50": _sig(out["single_query"]["wall_ms_p50"], 3),
+                                   "kernel_p50": _sig(out["single_query"]["kernel_ms_p50"], 3)}
     mg = c.get("multi_gpu")
     if mg:  # three numbers; per-rank lists, the broadcast report and the peer matrix are in the full record
         rates = mg.get("per_rank_queries_per_s") or [0.0]
@@ -403,7 +406,7 @@ def contract_line(out, names, main_name, full_path):
     line["full_record"] = full_path
     # what may go, in this order, if a line ever grows past the limit
     droppable = [("roofline", "traffic_over_algorithmic"), ("config", "launch"), ("config", "parallelism"), ("cpu_baseline", "sample"),
-                 (None, "two_launches_in_flight"), (None, "timed_regions"), (None, "multi_gpu")]
+                 (None, "single_query_ms"), (None, "two_launches_in_flight"), (None, "timed_regions"), (None, "multi_gpu")]
     text = json.dumps(line, separators=(",", ":"))
     while len(text.encode()) > CONTRACT_LINE_MAX:
         if droppable:
@@ -777,6 +780,28 @@ def run_config(ctx, args, config, main_line):
         view.status()
         view.close()
         del view, outs2
+    # ---- one query per call (rank-local, informational): the reference's published protocol is one search call per query
+    #      (experiments/run-benchmark.py:66-82).  Host buffers in, host buffers out, one caller thread: wall time per call and
+    #      the kernel's share of it (HIP events of the library), median of 200 calls at this configuration's ef.
+    single = None
+    if world == 1 and not args.no_secondary and main_line and rank == 0:
+        qs = Q_rank[0]  # (`_sh`: the uncounted entry point -- these are not NQ-query launches, see `launches` above)
+        for i in range(20):
+            _sh(qs[i % NQ:i % NQ + 1], K, EF)
+        walls, kerns = [], []
+        for i in range(200):
+            j = (20 + i) % NQ
+            t0 = time.perf_counter()
+            _sh(qs[j:j + 1], K, EF)
+            walls.append(time.perf_counter() - t0)
+            kerns.append(dev.last_kernel_ms())
+        g1 = dev.launch_geometry()
+        single = {"ef_search": EF, "calls": 200, "wall_ms_p50": float(np.percentile(walls, 50)) * 1e3,
+                  "wall_ms_p99": float(np.percentile(walls, 99)) * 1e3, "kernel_ms_p50": float(np.percentile(kerns, 50)),
+                  "value": 1.0 / float(np.mean(walls)), "unit": "queries/s", "lds_bytes_per_slot": g1["lds_bytes"],
+                  "note": "informational: one query per fnv_search_batch call from one thread, host buffers both ways"}
+        log("[rank 0] one query per call at ef=%d: wall p50 %.3f ms (p99 %.3f), kernel p50 %.3f ms, %.0f queries/s" % (
+            EF, single["wall_ms_p50"], single["wall_ms_p99"], single["kernel_ms_p50"], single["value"]))
     # ---- fixed-ef lines of this configuration (all ranks take part: the timing barrier is collective) ----------------
     secondary = []
     sustained = None
@@ -886,6 +911,7 @@ def run_config(ctx, args, config, main_line):
             "secondary": secondary,
             "sustained": sustained,
             "pipelined": pipelined,
+            "single_query": single,
         }
         if not main_line:  # a further configuration's entry: the notes that repeat the main line's are dropped
             out.pop("sustained")

@@ -68,7 +68,9 @@ def _full_entry(name, cpu=True, world=1):
                       "line_bytes_per_launch": 6415712345.5, "achieved_line_GBps": 6228.1, "avg_kernel_ms": 1.0301234,
                       "trace_position": {"timed": 20, "regions": 3, "after": 91}},
          "timed_regions": {"n": 3, "min": 9534766.1, "median": 9634766.123456789, "max": 9734766.9, "kernel_ms": [1.03, 1.031, 1.029], "note": "n" * 90},
-         "secondary": [], "sustained": {"value": 9.5e6}, "pipelined": {"value": 12034567.8, "note": "p" * 150}}
+         "secondary": [], "sustained": {"value": 9.5e6}, "pipelined": {"value": 12034567.8, "note": "p" * 150},
+         "single_query": {"ef_search": 1600, "calls": 200, "wall_ms_p50": 0.17234567, "wall_ms_p99": 0.189, "kernel_ms_p50": 0.13912345,
+                          "value": 5780.123, "unit": "queries/s", "lds_bytes_per_slot": 130160, "note": "s" * 100}}
     if cpu:
         e["cpu_baseline"] = {"value": 143630.123, "unit": "queries/s", "cores": 16, "kind": "port", "sample": "s" * 420,
                              "sample_short": "9 x first 10000 queries of batch 0, 16 threads (1 thread: 10912 q/s); GPU ids == CPU ids on "
@@ -110,6 +112,7 @@ def test_contract_line_of_a_seven_configuration_run_stays_under_4_kb():
     assert abs(r["traffic_over_algorithmic"] - 0.91) < 0.005 and r["avg_kernel_ms"] > 0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 16 and "100.00%" in d["cpu_baseline"]["sample"]
     assert d["value_pcie_inclusive"] == 8234567 and d["timed_regions"]["n"] == 3
+    assert d["single_query_ms"] == {"ef": 1600, "wall_p50": 0.172, "kernel_p50": 0.139}  # (one query per call: the reference's own protocol)
     rows = {row["config"]: row for row in d["secondary"] if row["config"] != "c2"}
     assert set(rows) == set(names) and "skipped" in rows["c5"] and rows["c4"]["frac"] == 0.779 and rows["c4"]["cpu"] > 0
     assert all(len(json.dumps(row)) <= 220 for row in d["secondary"])
