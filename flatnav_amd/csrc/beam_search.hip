@@ -1203,8 +1203,9 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   SearchParams p = sorted ? plan.sorted : plan.heaps;
   // Small launches on small indexes (round 5): when a bitmap of ALL node ids fits the LDS of the slots the launch needs, the
   // visited set is that bitmap (csrc/visited.hpp visited_insert_direct: one LDS round trip per link row, nothing overflows)
-  // instead of the tag table, and the launch runs the kernel's DIRECT instantiation -- a launch that leaves the GPU mostly idle is a chain of dependent latencies, and the tag table
-  // is 1.8 k of a lone hop's 7.9 k cycles.  The table is the last but two of the slot's LDS areas: only what follows it moves.
+  // instead of the tag table, and the launch runs the kernel's DIRECT instantiation -- a launch that leaves the GPU mostly idle
+  // is a chain of dependent latencies, and the tag table is 1.8 k of a lone hop's 7.9 k cycles.  The table is the last but
+  // two of the slot's LDS areas: only what follows it moves.
   // Only in launches that fill at most a quarter of the slots, and not when the caller has pinned the table's shape
   // ("visited_slots", "visited_tag_bits", "visited_wide"); "visited_direct" = 0 turns it off.
   const bool small_launch = 4 * nq <= (uint64_t)bpc * (uint64_t)ix->num_cus;  // (the condition of shadow mode)
