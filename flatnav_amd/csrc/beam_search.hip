@@ -255,6 +255,7 @@ struct fnv_index_s : IndexOptions {
   uint32_t* d_links = nullptr;
   int32_t* d_labels = nullptr;
   int num_cus = 0;
+  std::string gcn_arch;  // hipDeviceProp_t::gcnArchName: replicas on the same GPU model inherit the source's measurements
   uint64_t options_version = 0;
   LaunchPlan plan;
   // adaptive kernel choice ("sorted_beam" = 2): per beam width, the best time per query seen for each variant
@@ -336,6 +337,11 @@ struct fnv_index_s : IndexOptions {
   std::mutex lane_mu;            // creation of lanes
   uint64_t tune_epoch = 0;       // bumped whenever tuner / layouts change: a lane copies them when its own epoch lags
   uint64_t lane_epoch = ~0ull, lane_options = ~0ull;  // (on a lane: what it last copied from its owner)
+  // (on a replica, round 6) the handle fnv_replica_refresh last copied options from, that handle's options_version then, and
+  // the tune_epoch whose measurements this replica holds: fnv_search_batch_multi hands newer measurements over (pointer
+  // compared, never followed, outside calls that were given the source itself)
+  const fnv_index_s* replica_of = nullptr;
+  uint64_t replica_options = ~0ull, replica_epoch = ~0ull;
 };
 
 namespace {
@@ -344,6 +350,7 @@ int index_common_init(fnv_index_s* ix) {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, ix->device));
   ix->num_cus = prop.multiProcessorCount;
+  ix->gcn_arch = prop.gcnArchName;
   {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = 0;
@@ -1579,6 +1586,24 @@ int fnv_replicate(fnv_index_t src, int n_devices, const int* devices, fnv_index_
   return rc;
 }
 
+// What the source measured -- kernel variant per (beam width, batch class), LDS layout per beam width -- holds for a replica
+// on the same GPU model under the same options (round 6; before, a refresh cleared it and each of the seven replicas of an
+// 8-GPU run re-explored for up to 18 launches of its own).  Another GPU model starts empty and measures for itself.
+// Both handles' mutexes are held by the caller (source first).
+static void inherit_measurements(const fnv_index_s* src, fnv_index_s* r) {
+  const bool same_model = r->num_cus == src->num_cus && r->gcn_arch == src->gcn_arch;
+  if (same_model) {
+    r->tuner = src->tuner;
+    r->layouts = src->layouts;
+  } else {
+    r->tuner.clear();
+    r->layouts.clear();  // measured under the old options (a stale table size could even change the kernel mode)
+  }
+  r->sample_kernel = -1;
+  r->replica_epoch = src->tune_epoch;
+  r->tune_epoch++;  // (the replica's own lanes re-copy)
+}
+
 int fnv_replica_refresh(fnv_index_t src, int n_replicas, fnv_index_t* replicas) {
   if (!src || (!replicas && n_replicas)) return fail(FNV_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lock(src->mu);
@@ -1603,10 +1628,10 @@ int fnv_replica_refresh(fnv_index_t src, int n_replicas, fnv_index_t* replicas) 
     std::lock_guard<std::mutex> rl(r->mu);
     static_cast<IndexOptions&>(*r) = static_cast<const IndexOptions&>(*src);
     r->options_version++;
-    r->tuner.clear();
-    r->layouts.clear();  // measured under the old options (a stale table size could even change the kernel mode)
+    r->replica_of = src;
+    r->replica_options = src->options_version;
+    inherit_measurements(src, r);
     r->plan.valid = false;
-    r->sample_kernel = -1;
   }
   // Doubling tree of peer copies over xGMI: in every round each index that already holds the data feeds one that
   // does not (1 -> 2 -> 4 -> 8 holders: three rounds for eight GPUs, every link busy once per round).  The copies
@@ -1664,6 +1689,18 @@ int fnv_search_batch_multi(fnv_index_t* indexes, int n_indexes, const void* quer
   // host thread until the copy has been staged -- issued from ONE thread, GPU g+1 would not be launched before GPU g's
   // copy (and, on one stream per device, its kernel) had been waited for.  With a thread per device the staging copies,
   // launches and waits of all devices overlap, and hipSetDevice (per-thread state) never touches the caller's device.
+  // Replicas of indexes[0] take over what it has measured since their last refresh (fnv_tune on the source after
+  // fnv_replicate), as long as its options are still the ones they were given.
+  for (int g = 1; g < n_indexes; g++) {
+    fnv_index_t r = indexes[g], src = indexes[0];
+    if (r == src || r->replica_of != src) continue;
+    std::lock_guard<std::mutex> l1(src->mu);
+    std::lock_guard<std::mutex> l2(r->mu);
+    if (r->replica_options == src->options_version && r->replica_epoch != src->tune_epoch) {
+      inherit_measurements(src, r);
+      r->plan.valid = false;  // (a layout choice changes the plan)
+    }
+  }
   const uint64_t per = (nq + (uint64_t)n_indexes - 1) / (uint64_t)n_indexes;
   const size_t qrow = (size_t)indexes[0]->dim * dtype_size(indexes[0]->dtype);
   int shards = 0;

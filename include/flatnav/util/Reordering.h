@@ -3,16 +3,23 @@
 // Same entry points and contract as the reference (include/flatnav/util/Reordering.h:27-200):
 //   gOrder<node_id_t>(outdegree_table, w)  and  rcmOrder<node_id_t>(outdegree_table)
 // take table[node] = list of out-neighbours and return P with P[i] = NEW id of node i.
-// Out of the GPU hot path: these run once on the CPU.  A relabelling keeps the
-// graph isomorphic but moves which nodes the entry-point scan samples, so search results after a
-// reorder are statistically -- not bitwise -- equivalent (same in the reference).
+// Out of the GPU hot path: these run once on the CPU.
 //
-// gOrder: greedy sliding-window ordering (Wei et al., "Speedup Graph Processing by Graph
-// Ordering"): repeatedly append the unplaced node with the highest locality score against the
-// last `w` placed nodes; score(v) counts, for each window node u, edges u->v, edges v->u and
-// common in-neighbours.  Scores change by +-1, so a bucket queue gives O(1) updates.
-// rcmOrder: reverse Cuthill-McKee -- breadth-first from low-degree roots, neighbours expanded in
-// ascending degree, final order reversed.
+// Round 6: both return the SAME PERMUTATION as the reference, element for element -- pinned against the reference's own
+// header compiled where it lies (oracle/_ref: ref_gorder / ref_rcm; tests/test_reference_pins.py).  What makes a
+// permutation "the reference's" is how equal scores / equal degrees are resolved:
+//
+// gOrder (Wei et al., "Speedup Graph Processing by Graph Ordering"): greedy sliding window of w placed nodes; the score of
+// an unplaced node counts, per window node x, edges x->v, edges v->x and shared in-neighbours.  The reference keeps the
+// unplaced nodes in ONE array sorted by score (GorderPriorityQueue.h:14-109): +1 swaps the node with the LAST entry of
+// its score run, -1 with the FIRST, pop takes the array's back.  `ScoreRuns` below holds the same array, and instead of
+// the reference's two binary searches and hash map it keeps where each score's run starts and how long it is, so every
+// operation is O(1) and lands on the same position.
+//
+// rcmOrder: reverse Cuthill-McKee: roots by ascending out-degree, breadth-first, every node's out-neighbours enqueued by
+// ascending degree, final order reversed.  Equal degrees: the reference sorts (id, degree) pairs with std::sort on the
+// degree alone (Reordering.h:133-136, 154-157, 176-179) -- introsort is a function of the comparison outcomes only, so
+// std::sort over the ids with the same "degree less" predicate leaves equal-degree ids in the same places.
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -24,57 +31,75 @@ namespace flatnav::util {
 
 namespace detail {
 
-// Max-priority bucket queue over nodes 0..n-1 whose keys only ever move by one.
-// Buckets are doubly linked lists threaded through prev/next; pop() returns any node of the
-// highest non-empty bucket (most recently inserted first).
+// The unplaced nodes in one array ordered by ascending score; entries of equal score form a run.
 template <typename node_id_t>
-class UnitStepQueue {
-  static constexpr int64_t NIL = -1;
-  std::vector<int64_t> _prev, _next, _head;  // _head[key - _lo]
-  std::vector<int> _key;
-  std::vector<char> _present;
-  int _lo, _top;
+class ScoreRuns {
+  std::vector<node_id_t> _at;    // position -> node
+  std::vector<int64_t> _where;   // node -> position, -1 once placed
+  std::vector<int> _score;       // node -> score
+  // score s lives at runs[s - _base]: first position of its run, entries in it (first is meaningful while count > 0)
+  struct Run {
+    std::size_t first = 0, count = 0;
+  };
+  std::vector<Run> _runs;
+  int _base = 0;
+  std::size_t _size;
 
-  std::size_t slot(int key) {
-    if (key < _lo) {  // grow downwards
-      _head.insert(_head.begin(), static_cast<std::size_t>(_lo - key), NIL);
-      _lo = key;
+  Run& run(int s) {
+    if (s < _base) {
+      _runs.insert(_runs.begin(), static_cast<std::size_t>(_base - s), Run());
+      _base = s;
     }
-    std::size_t s = static_cast<std::size_t>(key - _lo);
-    if (s >= _head.size()) _head.resize(s + 1, NIL);
-    return s;
+    const std::size_t k = static_cast<std::size_t>(s - _base);
+    if (k >= _runs.size()) _runs.resize(k + 1);
+    return _runs[k];
   }
-  void unlink(node_id_t v) {
-    const int64_t p = _prev[v], n = _next[v];
-    if (p != NIL) _next[static_cast<std::size_t>(p)] = n;
-    else _head[static_cast<std::size_t>(_key[v] - _lo)] = n;
-    if (n != NIL) _prev[static_cast<std::size_t>(n)] = p;
-  }
-  void link(node_id_t v) {
-    const std::size_t s = slot(_key[v]);
-    _prev[v] = NIL;
-    _next[v] = _head[s];
-    if (_head[s] != NIL) _prev[static_cast<std::size_t>(_head[s])] = static_cast<int64_t>(v);
-    _head[s] = static_cast<int64_t>(v);
-    if (_key[v] > _top) _top = _key[v];
+  void exchange(std::size_t a, std::size_t b) {
+    std::swap(_at[a], _at[b]);
+    _where[_at[a]] = static_cast<int64_t>(a);
+    _where[_at[b]] = static_cast<int64_t>(b);
   }
 
  public:
-  explicit UnitStepQueue(std::size_t n) : _prev(n, NIL), _next(n, NIL), _key(n, 0), _present(n, 1), _lo(0), _top(0) {
-    _head.assign(1, NIL);
-    for (std::size_t v = n; v-- > 0;) link(static_cast<node_id_t>(v));  // node 0 ends up first
+  explicit ScoreRuns(std::size_t n) : _at(n), _where(n), _score(n, 0), _runs(1), _size(n) {
+    for (std::size_t v = 0; v < n; ++v) {
+      _at[v] = static_cast<node_id_t>(v);
+      _where[v] = static_cast<int64_t>(v);
+    }
+    _runs[0].count = n;
   }
-  void bump(node_id_t v, int delta) {
-    if (!_present[v]) return;
-    unlink(v);
-    _key[v] += delta;
-    link(v);
+  // score +1: the node trades places with the last entry of its run and becomes the first of the next run
+  void raise(node_id_t v) {
+    if (_where[v] < 0) return;
+    const int s = _score[v];
+    Run& from = run(s);
+    const std::size_t j = from.first + from.count - 1;
+    exchange(static_cast<std::size_t>(_where[v]), j);
+    from.count--;
+    Run& to = run(s + 1);  // (may reallocate: `from` is not used below)
+    to.first = j;
+    to.count++;
+    _score[v] = s + 1;
   }
-  node_id_t pop() {
-    while (_head[slot(_top)] == NIL) --_top;
-    const node_id_t v = static_cast<node_id_t>(_head[static_cast<std::size_t>(_top - _lo)]);
-    unlink(v);
-    _present[v] = 0;
+  // score -1: the node trades places with the first entry of its run and becomes the last of the run below
+  void lower(node_id_t v) {
+    if (_where[v] < 0) return;
+    const int s = _score[v];
+    const std::size_t j = run(s).first;
+    exchange(static_cast<std::size_t>(_where[v]), j);
+    Run& below = run(s - 1);  // (may reallocate)
+    if (below.count == 0) below.first = j;
+    below.count++;
+    Run& from = run(s);
+    from.first = j + 1;
+    from.count--;
+    _score[v] = s - 1;
+  }
+  // the back of the array: the last entry of the highest run
+  node_id_t take_back() {
+    const node_id_t v = _at[--_size];
+    run(_score[v]).count--;
+    _where[v] = -1;
     return v;
   }
 };
@@ -90,23 +115,26 @@ std::vector<node_id_t> gOrder(std::vector<std::vector<node_id_t>>& outdegree_tab
   for (std::size_t u = 0; u < n; ++u)
     for (node_id_t v : outdegree_table[u]) in_edges[v].push_back(static_cast<node_id_t>(u));
 
-  detail::UnitStepQueue<node_id_t> queue(n);
+  detail::ScoreRuns<node_id_t> unplaced(n);
   std::vector<node_id_t> order(n);
-  // score contribution of a window node `x` to every other node: +-1 per edge x->u, per edge
-  // u->x, and per shared in-neighbour relation (u->x and u->v).
-  auto touch = [&](node_id_t x, int delta) {
-    for (node_id_t u : outdegree_table[x]) queue.bump(u, delta);
+  // what a node x entering (up = true) or leaving the window does to every unplaced node's score: one step per edge x->u,
+  // per edge u->x, and per out-edge of such a u (u is a shared in-neighbour) -- in this order, which decides the ties
+  auto window_change = [&](node_id_t x, bool up) {
+    auto step = [&](node_id_t v) { up ? unplaced.raise(v) : unplaced.lower(v); };
+    for (node_id_t u : outdegree_table[x]) step(u);
     for (node_id_t u : in_edges[x]) {
-      queue.bump(u, delta);
-      for (node_id_t v : outdegree_table[u]) queue.bump(v, delta);
+      step(u);
+      for (node_id_t v : outdegree_table[u]) step(v);
     }
   };
-  queue.bump(0, 1);  // seed with node 0
-  order[0] = queue.pop();
+  unplaced.raise(0);  // node 0 seeds the order
+  order[0] = unplaced.take_back();
   for (std::size_t i = 1; i < n; ++i) {
-    touch(order[i - 1], +1);
-    if (i > static_cast<std::size_t>(w) + 1) touch(order[i - static_cast<std::size_t>(w) - 1], -1);
-    order[i] = queue.pop();
+    window_change(order[i - 1], true);
+    // (signed, as in the reference: a negative w makes every step i > w + 1 drop order[i - w - 1])
+    if (static_cast<int64_t>(i) > static_cast<int64_t>(w) + 1)
+      window_change(order[static_cast<std::size_t>(static_cast<int64_t>(i) - w - 1)], false);
+    order[i] = unplaced.take_back();
   }
   for (std::size_t pos = 0; pos < n; ++pos) new_id[order[pos]] = static_cast<node_id_t>(pos);
   return new_id;
@@ -115,14 +143,14 @@ std::vector<node_id_t> gOrder(std::vector<std::vector<node_id_t>>& outdegree_tab
 template <typename node_id_t>
 std::vector<node_id_t> rcmOrder(std::vector<std::vector<node_id_t>>& outdegree_table) {
   const std::size_t n = outdegree_table.size();
-  std::vector<std::size_t> degree(n);
+  std::vector<int> degree(n);
   std::vector<node_id_t> roots(n);
   for (std::size_t v = 0; v < n; ++v) {
-    degree[v] = outdegree_table[v].size();
+    degree[v] = static_cast<int>(outdegree_table[v].size());
     roots[v] = static_cast<node_id_t>(v);
   }
   auto by_degree = [&](node_id_t a, node_id_t b) { return degree[a] < degree[b]; };
-  std::stable_sort(roots.begin(), roots.end(), by_degree);
+  std::sort(roots.begin(), roots.end(), by_degree);  // NOT stable_sort: equal degrees as introsort leaves them (see top)
 
   std::vector<char> placed(n, 0);
   std::vector<node_id_t> order;
@@ -138,10 +166,11 @@ std::vector<node_id_t> rcmOrder(std::vector<std::vector<node_id_t>>& outdegree_t
       if (placed[v]) continue;
       placed[v] = 1;
       order.push_back(v);
+      // every out-neighbour is sorted (a placed one takes part in the sort's comparisons), the placed ones are skipped
+      // when they come up -- dropping them here instead would change where equal degrees land
       fringe.assign(outdegree_table[v].begin(), outdegree_table[v].end());
-      std::stable_sort(fringe.begin(), fringe.end(), by_degree);
-      for (node_id_t u : fringe)
-        if (!placed[u]) bfs.push(u);
+      std::sort(fringe.begin(), fringe.end(), by_degree);
+      for (node_id_t u : fringe) bfs.push(u);
     }
   }
   std::reverse(order.begin(), order.end());

@@ -10,7 +10,7 @@
 //  PINNING STATUS (read DESIGN.md "Oracle"):
 //    * distances  -- pinned: compared against the reference's own SIMD/scalar
 //      distance code compiled from /root/reference (oracle/_ref, see
-//      oracle/ref_distances.cpp) and against the reference's known answers
+//      oracle/ref_cereal_free.cpp) and against the reference's known answers
 //      (include/flatnav/tests/test_distances.cpp:84-100).
 //    * beam search / construction -- PARITY UNPINNED against an executed
 //      reference: flatnav/index/Index.h cannot be compiled in this image

@@ -90,6 +90,19 @@ def ref_lib():
         R.ref_vs_insert.argtypes = [C.c_void_p, C.c_uint32]
         R.ref_vs_is_visited.argtypes = [C.c_void_p, C.c_uint32]
         R.ref_vs_mark.argtypes = [C.c_void_p]
+        if hasattr(R, "ref_gorder"):  # round 6: Reordering.h, Multithreading.h, Datatype.h
+            R.ref_gorder.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+            R.ref_gorder.restype = None
+            R.ref_rcm.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+            R.ref_rcm.restype = None
+            R.ref_execute_in_parallel.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+            R.ref_datatype_name.restype = C.c_char_p
+            R.ref_datatype_name.argtypes = [C.c_int]
+            R.ref_datatype_ordinal.argtypes = [C.c_char_p]
+            for name in ("ref_datatype_size", "ref_datatype_ctype_bytes"):
+                getattr(R, name).restype = C.c_uint64
+                getattr(R, name).argtypes = [C.c_int]
+            R.ref_datatype_enum_bytes.restype = C.c_uint64
         _ref = R
     return _ref
 

@@ -25,6 +25,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long-running CPU test")
 
 
+# Result-pinning tests first, anything that measures time or drives many host threads last: under `-x` a late
+# failure can then never hide the parity suites.  Files not named keep their alphabetical place in the middle.
+_ORDER = ["test_golden", "test_gpu_parity", "test_gpu_round5", "test_gpu_round6", "test_gpu_configs", "test_cpp_api",
+          "test_gpu_python_api", "test_gpu_round4", "test_gpu_round3", "test_gpu_device_build", "test_gpu_fullsize",
+          "test_gpu_bench", "test_gpu_multi_device"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        if name in _ORDER:
+            return _ORDER.index(name) + (0 if _ORDER.index(name) < 5 else 1000)
+        return 500
+
+    items.sort(key=rank)  # stable: the order inside a file is kept
+
+
 @pytest.fixture(scope="session")
 def oracle_mod():
     from oracle import oracle as orc

@@ -35,6 +35,18 @@ def test_sift1m_shape_properties_and_parity(oracle_mod):
     o = oracle_mod.OracleIndex.from_blob("l2", "float32", 128, N, N, 32, np.asarray(index._raw_blob()))
     od, ol, ost = o.search(Q[:500], K, EF, threads=16, stats=True)
     assert np.array_equal(ol, l[:500]) and np.array_equal(od, d[:500])
+    import ctypes
+
+    from flatnav_amd import hip
+
+    dev = hip.DeviceIndex(ctypes.c_void_p(index.device_handle()), owned=False)
+    gd, gl, gst = dev.search(Q[:500], K, EF, stats=True)
+    assert np.array_equal(gl, ol) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+    assert np.array_equal(gst["n_dist"], ost["n_dist"]) and np.array_equal(gst["n_hops"], ost["n_hops"])
+    # ... and in the FULL launch (10 000 queries over the resident slots: rounds, hand-overs, the tuned variant)
+    fd, fl, fst = dev.search(Q, K, EF, stats=True)
+    assert np.array_equal(fl, l) and np.array_equal(fd.view(np.uint32), d.view(np.uint32))
+    assert np.array_equal(fst["n_dist"][:500], ost["n_dist"]) and np.array_equal(fst["n_hops"][:500], ost["n_hops"])
     # (5) the metric's recall bar, against exact brute force on the GPU
     xt, qt = torch.from_numpy(X).cuda(), torch.from_numpy(Q[:1000]).cuda()
     xn = (xt * xt).sum(1)
