@@ -335,6 +335,8 @@ struct fnv_index_s : IndexOptions {
   size_t lane_budget_bytes = 0;  // owner: budget for the hidden lanes' workspaces together (set at creation)
   std::atomic<fnv_index_s*> lanes[kMaxLanes] = {};  // [0] unused; written under lane_mu, read anywhere
   std::mutex lane_mu;            // creation of lanes
+  std::atomic<fnv_index_s*> last_served{nullptr};  // the lane that ran the handle's most recent launch (null: the handle itself):
+                                                   // fnv_last_kernel_ms / _replayed_queries / _handover_stats read ITS events and counters
   uint64_t tune_epoch = 0;       // bumped whenever tuner / layouts change: a lane copies them when its own epoch lags
   uint64_t lane_epoch = ~0ull, lane_options = ~0ull;  // (on a lane: what it last copied from its owner)
   // (on a replica, round 6) the handle fnv_replica_refresh last copied options from, that handle's options_version then, and
@@ -735,7 +737,10 @@ int fnv_set_option(fnv_index_t ix, const char* name, int64_t value) {
   else if (n == "tune_layout") ix->tune_layout = value;
   else if (n == "shadow_exact") ix->shadow_exact = value;
   else if (n == "tie_replay") ix->tie_replay = value;
-  else if (n == "tie_log_entries") ix->tie_log_entries = value;
+  else if (n == "tie_log_entries") {
+    if (value > (1 << 20)) return fail(FNV_ERR_INVALID, "tie_log_entries must be at most 1048576 records (8 MB per query slot)");
+    ix->tie_log_entries = value;
+  }
   else if (n == "visited_direct") ix->visited_direct = value;  // (read per launch)
   else return fail(FNV_ERR_INVALID, "unknown option: " + n);
   // What fnv_tune measured (kernel variant, LDS layout) stays valid across options that change neither the launch plan
@@ -951,32 +956,66 @@ static int grow(void** buf, size_t* have, size_t need, bool zero = false) {
   return FNV_OK;
 }
 
+// Set while fnv_tune / fnv_index_insert_batch run: this thread holds ix->lane_mu AND every lane's host_mu of that handle
+// (taken up front, so that no host-buffer search runs on a lane meanwhile).  release_idle_lanes then frees with the locks
+// it already has -- try_lock on a std::mutex the calling thread owns is undefined behaviour.
+static thread_local const fnv_index_s* t_holds_lanes_of = nullptr;
+struct HoldsLanes {
+  const fnv_index_s* before;
+  explicit HoldsLanes(const fnv_index_s* ix) : before(t_holds_lanes_of) { t_holds_lanes_of = ix; }
+  ~HoldsLanes() { t_holds_lanes_of = before; }
+};
+
+static size_t free_lane_workspace(fnv_index_s* l) {  // the caller owns l->host_mu
+  std::lock_guard<std::mutex> lk(l->mu);
+  DeviceScope scope(l->device);
+  size_t freed = 0;
+  void** bufs[] = {(void**)&l->d_bitmap, (void**)&l->d_ovf, (void**)&l->d_spill, (void**)&l->d_tielog};
+  size_t* sizes[] = {&l->bitmap_bytes, &l->ovf_bytes, &l->spill_bytes, &l->tielog_bytes};
+  for (int i = 0; i < 4; i++) {
+    if (*bufs[i]) (void)hipFree(*bufs[i]);
+    *bufs[i] = nullptr;
+    freed += *sizes[i];
+    *sizes[i] = 0;
+  }
+  l->ws_bytes = 0;
+  return freed;
+}
+
 // Frees the launch workspace of every hidden lane of `ix` that is idle right now (nobody inside a call on it), except
-// `keep`; returns the bytes released.  Never blocks: a lane in use, or a handle whose lanes are being created / held by
-// fnv_tune, is left alone.  The lanes re-grow on their next call.
-static size_t release_idle_lanes(fnv_index_s* ix, const fnv_index_s* keep) {
-  std::unique_lock<std::mutex> lanes_lock(ix->lane_mu, std::try_to_lock);
-  if (!lanes_lock.owns_lock()) return 0;
+// `keep`; returns the bytes released.  The caller holds ix->lane_mu.  `all_held`: it also holds every lane's host_mu.
+static size_t release_idle_lanes_locked(fnv_index_s* ix, const fnv_index_s* keep, bool all_held = false) {
   size_t freed = 0;
   for (std::atomic<fnv_index_s*>& slot : ix->lanes) {
     fnv_index_s* l = slot.load();
     if (!l || l == keep) continue;
-    std::unique_lock<std::mutex> idle(l->host_mu, std::try_to_lock);
-    if (!idle.owns_lock()) continue;
-    std::lock_guard<std::mutex> lk(l->mu);
-    DeviceScope scope(l->device);
-    void** bufs[] = {(void**)&l->d_bitmap, (void**)&l->d_ovf, (void**)&l->d_spill, (void**)&l->d_tielog};
-    size_t* sizes[] = {&l->bitmap_bytes, &l->ovf_bytes, &l->spill_bytes, &l->tielog_bytes};
-    for (int i = 0; i < 4; i++) {
-      if (*bufs[i]) (void)hipFree(*bufs[i]);
-      *bufs[i] = nullptr;
-      freed += *sizes[i];
-      *sizes[i] = 0;
+    if (all_held) {
+      freed += free_lane_workspace(l);
+      continue;
     }
-    l->ws_bytes = 0;
+    std::unique_lock<std::mutex> idle(l->host_mu, std::try_to_lock);
+    if (idle.owns_lock()) freed += free_lane_workspace(l);
   }
   (void)hipGetLastError();
   return freed;
+}
+// ... for a caller that holds nothing of the lanes.  Never blocks: a lane in use, or a handle whose lanes are being created /
+// held by another thread's fnv_tune, is left alone.  The lanes re-grow on their next call.
+static size_t release_idle_lanes(fnv_index_s* ix, const fnv_index_s* keep) {
+  if (t_holds_lanes_of == ix) return release_idle_lanes_locked(ix, keep, /*all_held=*/true);
+  std::unique_lock<std::mutex> lanes_lock(ix->lane_mu, std::try_to_lock);
+  if (!lanes_lock.owns_lock()) return 0;
+  return release_idle_lanes_locked(ix, keep);
+}
+
+// Records of the hand-over log per query slot (kernels.hpp): a query logs ~6 records per beam entry on the reference workloads
+// (1M x 128 at ef=52: ~310; a hop is a header + the row's admissible neighbours); 24 per entry + 512, in [1024, 16384] records
+// of 8 bytes per slot = 8-128 KB, or what "tie_log_entries" says (in [WAVE + 2, 2^20]).  A log that overflows ends (the query
+// is searched again from scratch if equal keys meet).
+static uint32_t log_entries_for(const fnv_index_s* ix, int B) {
+  if (!ix->tie_replay) return 0u;
+  if (ix->tie_log_entries) return (uint32_t)std::min<int64_t>(1 << 20, std::max<int64_t>(WAVE + 2, ix->tie_log_entries));
+  return std::min<uint32_t>(16384u, std::max<uint32_t>(1024u, pow2_ceil(24ull * (uint64_t)B + 512)));
 }
 
 // HBM a launch of `nq` queries needs as per-slot workspace on a handle of this index (what search_device_impl grows).
@@ -986,7 +1025,8 @@ static size_t launch_workspace_bytes(fnv_index_s* ix, uint64_t nq) {
   const uint64_t ovf_cap = ix->overflow_list >= 0 ? (uint64_t)ix->overflow_list : (bitmap_words * 4 > (512u << 10) ? 16384u : 0u);
   const int per_cu = ix->plan.valid ? std::max(ix->plan.bpc, ix->plan.sbpc) : 32;  // (no plan yet: the hardware's 32 waves per CU)
   const uint64_t slots = std::min<uint64_t>(2 * nq, (uint64_t)per_cu * (uint64_t)ix->num_cus);  // (small launches: a shadow per query)
-  const uint64_t log_entries = ix->plan.valid ? ix->plan.sorted.log_entries : 16384u;
+  // (the plan's own formula -- plan.sorted is unset while the plan runs the two-heap kernel only; no plan yet: the largest automatic log)
+  const uint64_t log_entries = ix->plan.valid ? log_entries_for(ix, ix->plan.B) : (ix->tie_replay ? std::max<uint64_t>(16384u, (uint64_t)ix->tie_log_entries) : 0u);
   return (size_t)(slots * (bitmap_words * 4 + ovf_cap * 4 + (uint64_t)ix->spill_entries * 8 + log_entries * 8));
 }
 
@@ -1034,12 +1074,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     p.bitmap_words = (uint32_t)(((ix->capacity + 31) / 32 + 3) / 4 * 4);  // whole 16-byte groups: wide clears
     p.ovf_cap = ix->overflow_list >= 0 ? (uint32_t)ix->overflow_list
                                        : ((uint64_t)p.bitmap_words * 4 > (512u << 10) ? 16384u : 0u);
-    // hand-over log (kernels.hpp): a query logs ~6 records per beam entry on the reference workloads (1M x 128 at ef=52: ~310;
-    // a hop is a header + the row's admissible neighbours); 24 per entry + 512, in [1024, 16384] records of 8 bytes per slot
-    // = 8-128 KB.  A log that overflows ends (the query is searched again from scratch if equal keys meet).
-    p.log_entries = !ix->tie_replay ? 0u
-                    : ix->tie_log_entries ? (uint32_t)std::max<int64_t>(WAVE + 2, ix->tie_log_entries)
-                                          : std::min<uint32_t>(16384u, std::max<uint32_t>(1024u, pow2_ceil(24ull * (uint64_t)p.B + 512)));
+    p.log_entries = log_entries_for(ix, p.B);
     const bool full = (p.nchunks % per_iter) == 0;  // rows are whole spans: the lean FULL kernels apply
     plan.cfg = cfg;
     plan.full = full;
@@ -1199,9 +1234,9 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     if (!rc && (shadow || tail_shadows)) rc = grow((void**)&ix->d_done, &ix->done_bytes, (size_t)nq * 4);
     if (!rc && sorted) rc = grow((void**)&ix->d_tielog, &ix->tielog_bytes, (size_t)max_slots * plan.sorted.log_entries * 8);
     ix->ws_bytes = ix->bitmap_bytes + ix->ovf_bytes + ix->spill_bytes + ix->tielog_bytes;
-    // out of memory on the handle itself: the hidden lanes' idle workspaces go first, then once more (not from inside
-    // fnv_tune, which holds the lanes)
-    if (rc != FNV_ERR_NO_DEVICE || attempt || ix->is_lane || ix->parent || force_variant >= 0) break;
+    // out of memory on the handle itself: the hidden lanes' idle workspaces go first, then once more (from inside fnv_tune /
+    // fnv_index_insert_batch, which hold the lanes, with the locks already held: t_holds_lanes_of)
+    if (rc != FNV_ERR_NO_DEVICE || attempt || ix->is_lane || ix->parent) break;
     (void)hipGetLastError();
     if (release_idle_lanes(ix, nullptr) == 0) break;
   }
@@ -1312,6 +1347,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
   ix->last_shadow = shadow;
   ix->last_stream = stream;
   ix->launched = true;
+  if (!ix->is_lane) ix->last_served = nullptr;  // the handle's own launch is its most recent one
   ix->geom[0] = nslots;
   ix->geom[1] = WAVE;
   ix->geom[2] = lds_bytes;
@@ -1464,16 +1500,14 @@ static int check_search_args(fnv_index_t ix, const void* queries, uint64_t nq, i
   return FNV_OK;
 }
 
-// Hidden lane `which` (1 ... kMaxLanes - 1) of a handle (fnv_index_s::lanes): created on first contention.
-static fnv_index_s* hidden_lane(fnv_index_t ix, int which) {
-  std::lock_guard<std::mutex> lock(ix->lane_mu);
-  if (!ix->lanes[which].load()) {
-    fnv_index_t v = nullptr;
-    if (fnv_index_view(ix, &v) != FNV_OK) return nullptr;
-    v->is_lane = true;
-    ix->lanes[which] = v;
-  }
-  return ix->lanes[which].load();
+// Hidden lane `which` (1 ... kMaxLanes - 1) of a handle (fnv_index_s::lanes): created on first contention, by a caller that
+// holds ix->lane_mu and has been admitted (a lane costs a stream, two events, a dispenser and 1 MB of pinned host memory).
+static fnv_index_s* create_lane_locked(fnv_index_t ix, int which) {
+  fnv_index_t v = nullptr;
+  if (fnv_index_view(ix, &v) != FNV_OK) return nullptr;
+  v->is_lane = true;
+  ix->lanes[which] = v;
+  return v;
 }
 // The lane answers exactly like its owner: same options, same measured layouts and kernel choice (copied when they changed).
 static void sync_lane(fnv_index_t ix, fnv_index_s* lane) {
@@ -1509,22 +1543,40 @@ int fnv_search_batch(fnv_index_t ix, const void* queries, uint64_t nq, int K, in
     // A lane is taken only if the HBM its launch workspace needs fits the budget for all hidden lanes together (round 5;
     // fnv_index_s: an eighth of the device's memory) -- measured on 1M x 128 (r4_run18): 7.8 / 10.4 / 11.2 / 11.5 M queries/s
     // from 1 / 2 / 3 / 4 caller threads on four lanes; at 50M nodes one full-grid lane is 19 GB and the second does not fit.
+    // Admission, reservation and creation happen under lane_mu: two concurrent callers cannot both pass the budget
+    // test, and a batch that fits no lane (large index, FLATNAV_LANE_BUDGET_MB=0) creates none.  Lock order: lane_mu, then a
+    // lane's host_mu by try_lock only (fnv_tune takes lane_mu, then every lane's host_mu, blocking).
     const size_t need = launch_workspace_bytes(ix, nq);
-    for (int which = 1; which < fnv_index_s::kMaxLanes && !host_lock.owns_lock(); which++) {
-      if (fnv_index_s* l = hidden_lane(ix, which)) {
-        std::unique_lock<std::mutex> lock2(l->host_mu, std::try_to_lock);
-        if (!lock2.owns_lock()) continue;
+    if (need <= ix->lane_budget_bytes) {
+      std::lock_guard<std::mutex> admission(ix->lane_mu);
+      for (int which = 1; which < fnv_index_s::kMaxLanes; which++) {
+        fnv_index_s* l = ix->lanes[which].load();
+        std::unique_lock<std::mutex> lock2;
+        if (l) {
+          lock2 = std::unique_lock<std::mutex>(l->host_mu, std::try_to_lock);
+          if (!lock2.owns_lock()) continue;
+        }
         auto others = [&]() {
           size_t sum = 0;
           for (int o = 1; o < fnv_index_s::kMaxLanes; o++)
             if (fnv_index_s* other = o != which ? ix->lanes[o].load() : nullptr) sum += other->ws_bytes.load();
           return sum;
         };
-        const size_t mine = std::max<size_t>(l->ws_bytes.load(), need);
-        if (others() + mine > ix->lane_budget_bytes) (void)release_idle_lanes(ix, l);  // idle lanes give their room back first
-        if (others() + mine > ix->lane_budget_bytes) continue;                          // does not fit: not this lane
+        const size_t mine = std::max<size_t>(l ? l->ws_bytes.load() : 0, need);
+        if (others() + mine > ix->lane_budget_bytes) (void)release_idle_lanes_locked(ix, l);  // idle lanes give their room back first
+        if (others() + mine > ix->lane_budget_bytes) {
+          if (!l) break;  // no further lane would fit either
+          continue;       // does not fit: not this lane
+        }
+        if (!l) {
+          l = create_lane_locked(ix, which);
+          if (!l) break;
+          lock2 = std::unique_lock<std::mutex>(l->host_mu);
+        }
+        l->ws_bytes = mine;  // the reservation: visible to the next caller's budget test before lane_mu is released
         lane = l;
         host_lock = std::move(lock2);
+        break;
       }
     }
   }
@@ -1553,6 +1605,7 @@ int fnv_search_batch(fnv_index_t ix, const void* queries, uint64_t nq, int K, in
     ix->last_exploratory = lane->last_exploratory;
     ix->last_shadow = lane->last_shadow;
     for (int i = 0; i < 8; i++) ix->geom[i] = lane->geom[i];
+    ix->last_served = lane;  // (lanes live as long as the handle)
   }
   return rc;
 }
@@ -1741,6 +1794,7 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
   std::vector<std::unique_lock<std::mutex>> lane_locks;
   for (std::atomic<fnv_index_s*>& slot : ix->lanes)
     if (fnv_index_s* l = slot.load()) lane_locks.emplace_back(l->host_mu);
+  HoldsLanes holds_lanes(ix);
   ON_DEVICE(ix->device);
   const size_t qbytes = (size_t)nq * ix->dim * dtype_size(ix->dtype);
   const size_t o_lab = (size_t)nq * K * 4, obytes = 2 * o_lab;
@@ -1812,8 +1866,14 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
   // the common cases (configure_launch), this measures the neighbours of the rule's choice -- heap home flipped, the
   // table one size up / down -- with the merged-beam kernel alone and with its whole last round straight to the exact
   // search, and keeps the fastest.  Skipped for whatever the caller pinned with an option.
-  const uint32_t base_slots = (uint32_t)ix->geom[4];
-  const bool base_heap_lds = ix->geom[5] != 0;
+  // (from the plan, not from the probing launch's geometry record: a DIRECT launch reports its bitmap's bits there)
+  uint32_t base_slots = 0;
+  bool base_heap_lds = false;
+  {
+    std::lock_guard<std::mutex> lock(ix->mu);
+    base_slots = ix->plan.sorted.vis_slots;
+    base_heap_lds = ix->plan.sorted.cand_slots != 0;
+  }
   std::vector<fnv_index_s::LayoutChoice> cands(1);  // [0]: the rules
   if (ix->tune_layout && ix->sorted_cand_lds == 2) {
     fnv_index_s::LayoutChoice c;
@@ -1988,6 +2048,7 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
   std::vector<std::unique_lock<std::mutex>> lane_locks;
   for (std::atomic<fnv_index_s*>& slot : ix->lanes)
     if (fnv_index_s* l = slot.load()) lane_locks.emplace_back(l->host_mu);
+  HoldsLanes holds_lanes(ix);
   ON_DEVICE(ix->device);
   const int W = ef_construction;
   const uint32_t keep = std::max<uint32_t>(ix->M / 2, 1);  // Index.h:373
@@ -2120,8 +2181,15 @@ int fnv_index_read_links(fnv_index_t ix, uint64_t first_node, uint64_t count, ui
   return FNV_OK;
 }
 
+// The handle whose events / counters describe the most recent launch of `ix`: a hidden lane if that served the last host-buffer call.
+static fnv_index_s* last_launcher(fnv_index_t ix) {
+  fnv_index_s* lane = ix->last_served.load();
+  return lane ? lane : ix;
+}
+
 int fnv_last_kernel_ms(fnv_index_t ix, float* ms) {
   if (!ix || !ms) return fail(FNV_ERR_INVALID, "null argument");
+  ix = last_launcher(ix);
   if (!ix->launched) return fail(FNV_ERR_RUNTIME, "no search has been launched on this index");
   ON_DEVICE(ix->device);
   HIP_TRY(hipEventSynchronize(ix->ev1));
@@ -2153,6 +2221,7 @@ int fnv_debug_phase_cycles(fnv_index_t ix, uint64_t out[16]) {
 int fnv_last_replayed_queries(fnv_index_t ix, uint64_t out[5]) {
   if (!ix || !out) return fail(FNV_ERR_INVALID, "null argument");
   for (int i = 0; i < 5; i++) out[i] = 0;
+  ix = last_launcher(ix);
   if (!ix->launched) return FNV_OK;
   ON_DEVICE(ix->device);
   HIP_TRY(hipStreamSynchronize(ix->last_stream));
@@ -2165,6 +2234,7 @@ int fnv_last_replayed_queries(fnv_index_t ix, uint64_t out[5]) {
 int fnv_last_handover_stats(fnv_index_t ix, uint64_t out[4]) {
   if (!ix || !out) return fail(FNV_ERR_INVALID, "null argument");
   for (int i = 0; i < 4; i++) out[i] = 0;
+  ix = last_launcher(ix);
   if (!ix->launched) return FNV_OK;
   ON_DEVICE(ix->device);
   HIP_TRY(hipStreamSynchronize(ix->last_stream));

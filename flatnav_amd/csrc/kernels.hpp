@@ -382,7 +382,7 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, const Query<G, CU
   __syncthreads();
 
   while (true) {
-    if (s.cand_n <= 0) break;
+    if (s.cand_n <= 0 || s.err) break;  // (s.err: a replayed log that overflowed the candidates heap -- no hop on that state)
     const fnv_stl::Entry ctop = exact_cand_top(x, cand, spill);
     const float ctop_d = -rfl(ctop.key);
     if (ctop_d > s.max_dist && s.nbr_n >= B) break;  // Index.h:630
