@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- QPS of the batched flat-NSW k-NN search on MI355X, one line per BASELINE.json configuration.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c3-lowrank|c4|c5|c5-lowrank]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c2-uint8|c3|c3-lowrank|c4|c5|c5-lowrank|c5-uint8]
                   [--secondary-configs c4,c3-lowrank,c5,c5-lowrank | none] [--index-size n ...]
 
 One "step" = one pass of the hot path over one batch: `nq` queries (10 000) searched against an index resident in
@@ -13,6 +13,7 @@ Configurations (BASELINE.json `configs`, generators of SURVEY.md 8d; no dataset 
   c4            GloVe-1.2M stand-in: 1 183 514 x 100 low-rank unit vectors, IP     ef sweep 50..400, value at the recall rule
   c5            50M x 128 randn, L2, index replicated per GPU, queries sharded     ef=100 as worded (recall is hopeless)
   c5-lowrank    50M x 128 S1 generator (the SIFT stand-in at N=50M), L2            ef by the recall rule
+  c2-uint8 / c5-uint8   the c2 / c5-lowrank data stored as bytes (integer datasets: bit-exact ids), L2   ef by the recall rule
 All with M=32, ef_construction=100, K=10.  The metric's rule: the smallest ef of the sweep with recall@10 >= 0.95,
 recall measured on all 10 000 queries of the first batch against exact brute force.
 
@@ -24,7 +25,7 @@ vector table reaches, measured in the run), `cpu_baseline` (N=1: the CPU oracle 
 `timed_regions` (value = the median of --regions timed regions of --steps launches each; min / max beside it) and
 `secondary`: one short row per fixed-ef line and per FURTHER CONFIGURATION.  Those run after the main one in the same
 process -- like the reference's harness, which runs a list of datasets and ef values in one invocation
-(experiments/run-benchmark.py:362-506, tools/query_npy.cpp:132-158) -- N = 1: c2-uint8, c4, c3-lowrank, c3, c5, c5-lowrank;
+(experiments/run-benchmark.py:362-506, tools/query_npy.cpp:132-158) -- N = 1: c2-uint8, c4, c3-lowrank, c3, c5, c5-lowrank, c5-uint8;
 N > 1 GPUs: only c5, the configuration worded for 8 GPUs; `--secondary-configs none` turns them off, `--time-budget` skips
 what no longer fits.  The FULL record -- every configuration's whole entry (own recall / ef rule, roofline, counters,
 cpu_baseline with GPU ids == CPU ids, sustained and two-launches-in-flight rates, per-rank and broadcast reports) -- is
@@ -74,9 +75,14 @@ CONFIGS = {
     "c2-uint8": dict(gen="sift_like", n=1_000_000, dim=128, metric="l2", ef=0, dtype="uint8",
                      sweep=[30, 40, 44, 48, 50, 52, 54, 56, 58, 60, 64, 70, 80, 100, 150, 200, 400], secondary=[],
                      title="SIFT-1M stand-in stored as uint8 (same integer-valued data as c2)"),
+    # ... and at a size where HBM, not the Infinity Cache, is the roof (the reference's large sets are uint8:
+    # experiments/data_loader.py:170-219 reads .u8bin): the c5-lowrank data stored as bytes, 6.4 GB of vectors + 6.4 GB of links
+    "c5-uint8": dict(gen="sift_like", n=50_000_000, dim=128, metric="l2", ef=0, dtype="uint8",
+                     sweep=[50, 64, 72, 76, 78, 80, 100, 128, 160, 200, 300, 400, 600], secondary=[],
+                     title="the S1 SIFT stand-in generator at N=50M stored as uint8 (integer dataset at HBM scale)"),
 }
 # world size -> configurations after the main one (else: "c5")
-SECONDARY_DEFAULT = {1: "c2-uint8,c4,c3-lowrank,c3,c5,c5-lowrank"}
+SECONDARY_DEFAULT = {1: "c2-uint8,c4,c3-lowrank,c3,c5,c5-lowrank,c5-uint8"}
 
 
 def log(*a):
@@ -343,8 +349,13 @@ def contract_line(out, names, main_name, full_path):
     traffic_rec = (r.get("traffic_recorded") or {}).get("hbm_bytes_per_launch_corrected")
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                 "scaling", "vs_baseline", "dtype", "data")}
+    #  which rate `value` is, in the line itself: the contract's device-resident rate; SURVEY 8d words the metric
+    # on the call that includes the copies -- that number rides along as `value_pcie_inclusive`, named here
+    what = "; value = device-resident rate (queries and results in HBM when the timed region starts)"
+    if c.get("host_buffer_qps_pcie_inclusive"):
+        what += ", SURVEY 8d's PCIe-inclusive rate (host buffers both ways) = %d queries/s = value_pcie_inclusive" % c["host_buffer_qps_pcie_inclusive"]
     line["config"] = {
-        "workload": c["workload"][:320],
+        "workload": c["workload"][:320] + what,
         "ef_search": c["ef_search"],
         "recall_at_10": c["recall_at_10"],
         "recall_min_over_timed_batches": c["recall_all_timed_batches"]["min"],
@@ -372,6 +383,9 @@ def contract_line(out, names, main_name, full_path):
     line["value_pcie_inclusive"] = c.get("host_buffer_qps_pcie_inclusive")
     line["timed_regions"] = {k: (_sig(v) if not isinstance(v, list) else [_sig(x, 4) for x in v])
                              for k, v in (out.get("timed_regions") or {}).items() if k != "note"} or None
+    if out.get("sustained"):  # >= 1 s of back-to-back steps: the timed region of the contract (--steps launches) is ~20 ms
+        line["sustained"] = {"value": _sig(out["sustained"]["value"]), "seconds": _sig(out["sustained"]["seconds"], 3),
+                             "steps": out["sustained"]["steps"]}
     if out.get("pipelined"):
         line["two_launches_in_flight"] = _sig(out["pipelined"]["value"])
     if out.get("single_query"):
@@ -406,7 +420,7 @@ def contract_line(out, names, main_name, full_path):
     line["full_record"] = full_path
     # what may go, in this order, if a line ever grows past the limit
     droppable = [("roofline", "traffic_over_algorithmic"), ("config", "launch"), ("config", "parallelism"), ("cpu_baseline", "sample"),
-                 (None, "single_query_ms"), (None, "two_launches_in_flight"), (None, "timed_regions"), (None, "multi_gpu")]
+                 (None, "single_query_ms"), (None, "two_launches_in_flight"), (None, "timed_regions"), (None, "multi_gpu"), (None, "sustained")]
     text = json.dumps(line, separators=(",", ":"))
     while len(text.encode()) > CONTRACT_LINE_MAX:
         if droppable:
@@ -419,7 +433,7 @@ def contract_line(out, names, main_name, full_path):
         elif line["secondary"]:
             line["secondary"].pop()
         else:
-            line["config"]["workload"] = line["config"]["workload"][:100]
+            line["config"]["workload"] = line["config"]["workload"][:100] + what[:70]
             text = json.dumps(line, separators=(",", ":"))
             break
         text = json.dumps(line, separators=(",", ":"))
@@ -550,8 +564,10 @@ def run_config(ctx, args, config, main_line):
 
     dev.search_device, dev.search = _count_device, _count_host
     ROW = dev.row_bytes  # bytes one row occupies in HBM (>= DIM * ESIZE: 16-byte chunks, whole 128-byte lines when cheap)
+    TAIL = getattr(dev, "tail_bytes", 0)  # split rows (round 6): the row's last chunks live in a small cache-resident side table
     # bytes of the 128-byte lines one row touches: the stride itself when rows are whole lines, else the expectation for
-    # a row that starts at a random 16-byte boundary inside a line
+    # a row that starts at a random 16-byte boundary inside a line (split rows: the main table's lines; the side table is
+    # meant to be served from L2 / Infinity Cache)
     LINE_ROW = ROW if ROW % 128 == 0 else ROW + 112
 
     # ---- device-resident inputs / outputs -----------------------------------------------------------------------
@@ -824,7 +840,7 @@ def run_config(ctx, args, config, main_line):
         kname = {"two_heaps": "fnv_dev::beam_search_kernel",
                  "merged_beam_registers": "fnv_dev::beam_search_merged_kernel",
                  "merged_beam_lds": "fnv_dev::beam_search_merged_kernel"}[geom["kernel"]]
-        index_bytes = N * (ROW + 4 * M + 4)
+        index_bytes = N * (ROW + TAIL + 4 * M + 4)
         out = {
             "metric": "qps_at_recall10_ge_0.95",
             "value": main_m["qps"],
@@ -890,14 +906,16 @@ def run_config(ctx, args, config, main_line):
                 "gather_ceiling": ceiling,
                 "frac_of_gather_ceiling": main_m["achieved"] / ceiling,
                 "gather_ceiling_note": "fnv_gather_ceiling, measured in this run: GB/s of algorithmic row bytes that a pure "
-                                       "gather of random rows of THIS vector table (%d-byte rows at a %d-byte stride, "
+                                       "gather of random rows of THIS vector table (%d-byte rows at a %d-byte stride%s, "
                                        "%.2f GB) reaches with the search kernel's load pattern at %d waves per CU and no "
-                                       "other work" % (DIM * ESIZE, ROW, N * ROW / 1e9, geom["blocks_per_cu"]),
+                                       "other work" % (DIM * ESIZE, ROW, " + %d bytes per row in the side table (not gathered here)" % TAIL if TAIL else "",
+                                                       N * ROW / 1e9, geom["blocks_per_cu"]),
                 "traffic": None,
                 "traffic_recorded": recorded_traffic(config, DT, N, NQ, EF),
                 "algorithmic_bytes_per_launch": main_m["bytes"],
                 "row_bytes": DIM * ESIZE,
                 "row_stride_bytes": ROW,
+                "row_tail_bytes": TAIL,
                 "line_bytes_per_launch": main_m["row_bytes"],
                 "achieved_line_GBps": main_m["row_bytes"] / (main_m["kernel_ms"] / 1e3) / 1e9,
                 "avg_kernel_ms": main_m["kernel_ms"],
@@ -942,16 +960,23 @@ def exact_topk(torch, dev, q, K, N, DIM, DT, metric, block=250_000):
 
     (vptr, vbytes), _, _ = dev.device_buffers()
     row_bytes = dev.row_bytes
+    tail_bytes = getattr(dev, "tail_bytes", 0)
     dev_t = q.device
     table = torch.as_tensor(multigpu._DevView(vptr, N * row_bytes), device=dev_t)
+    tails = None
+    if tail_bytes:  # split rows: the side table follows the main table of the handle's capacity
+        capacity = vbytes // (row_bytes + tail_bytes)
+        tails = torch.as_tensor(multigpu._DevView(vptr + capacity * row_bytes, N * tail_bytes), device=dev_t)
     qf = q.float()
     best_s = torch.full((q.shape[0], K), float("inf"), device=dev_t)
     best_i = torch.zeros((q.shape[0], K), dtype=torch.int64, device=dev_t)
     for s in range(0, N, block):
         e = min(N, s + block)
         rows = table[s * row_bytes:e * row_bytes].view(e - s, row_bytes)
+        if tails is not None:
+            rows = torch.cat([rows, tails[s * tail_bytes:e * tail_bytes].view(e - s, tail_bytes)], dim=1)
         if DT == "float32":
-            x = rows.view(torch.float32)[:, :DIM]
+            x = rows.contiguous().view(torch.float32)[:, :DIM]
         else:
             x = rows[:, :DIM].float()
         for qs in range(0, qf.shape[0], 2500):
@@ -977,8 +1002,9 @@ def recorded_traffic(config, dtype, n, nq, ef):
     """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate runs, corrected as MI355X_MICROARCH.md prescribes) -- a RECORDED number, labelled as such; None unless
     the committed passes profiled this very workload."""
-    config = config.replace("-uint8", "")  # (the uint8 index is recorded as config c2, dtype uint8)
-    for name in ("r5_pmc_hbm_traffic.json", "r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "pmc_hbm_traffic.json"):
+    if config == "c2-uint8":
+        config = "c2"  # (the 1M uint8 index is recorded as config c2, dtype uint8)
+    for name in ("r6_pmc_hbm_traffic.json", "r5_pmc_hbm_traffic.json", "r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "pmc_hbm_traffic.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):

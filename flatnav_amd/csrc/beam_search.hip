@@ -248,6 +248,10 @@ struct fnv_index_s : IndexOptions {
   int device = 0;
   int dtype = FNV_DTYPE_FLOAT32, metric = FNV_METRIC_L2;
   uint32_t M = 0, dim = 0, row_bytes = 0;
+  uint32_t tail_bytes = 0;  // split rows (distance.hpp, row_layout below): bytes per row in the side table that follows the main
+                            // table in d_vectors' allocation ([capacity][row_bytes] main, then [capacity][tail_bytes]); 0: one table
+  const uint8_t* tails() const { return tail_bytes ? d_vectors + capacity * (uint64_t)row_bytes : nullptr; }
+  uint64_t vector_bytes() const { return capacity * ((uint64_t)row_bytes + tail_bytes); }
   std::atomic<uint64_t> n_nodes{0};  // live nodes: what a search sees (entry scan, id range); a view reads its source's at
                                      // every launch while the source may be growing -> atomic
   uint64_t capacity = 0;  // rows the device buffers hold (>= n_nodes; grows never)
@@ -382,7 +386,7 @@ int validate_geometry(uint32_t M, uint64_t n_nodes, int data_type, int metric, u
 }
 
 int alloc_buffers(fnv_index_s* ix) {  // the caller is on ix->device
-  HIP_TRY(hipMalloc(&ix->d_vectors, ix->capacity * (uint64_t)ix->row_bytes));
+  HIP_TRY(hipMalloc(&ix->d_vectors, ix->vector_bytes()));
   HIP_TRY(hipMalloc(&ix->d_links, ix->capacity * (uint64_t)ix->M * 4));
   HIP_TRY(hipMalloc(&ix->d_labels, ix->capacity * 4));
   return index_common_init(ix);
@@ -401,6 +405,26 @@ uint32_t row_stride_bytes(uint32_t dim, int data_type) {
   if (const char* env = getenv("FLATNAV_ROW_PAD_PCT")) pct = strtol(env, nullptr, 10);
   if (pct > 0 && (rb128 - rb16) * 100 <= (uint64_t)pct * rb16) return (uint32_t)rb128;
   return (uint32_t)rb16;
+}
+
+// SPLIT ROWS (round 6, distance.hpp): a row of exactly three 128-byte lines plus at most 32 bytes (d = 97 ... 104 float32, 385 ... 416
+// one-byte elements) keeps its whole lines in the main table (stride 384) and its last one or two chunks in a dense side
+// table -- as long as that table stays small enough to live in L2 / Infinity Cache (FLATNAV_SPLIT_TAIL_MAX_MB, default 64 MB:
+// 4 M rows of 16 bytes), where the fourth request of a gather no longer costs an HBM line that is 7/8 padding.
+// FLATNAV_SPLIT_ROWS=0 turns it off (rows are then padded to four lines, as in rounds 2-5).  Every handle on the same
+// buffers (views, fnv_index_adopt, replicas, the ranks of a broadcast) derives the same layout from (dim, type, capacity).
+struct RowLayout {
+  uint32_t row_bytes, tail_bytes;
+};
+RowLayout row_layout(uint32_t dim, int data_type, uint64_t capacity) {
+  const uint64_t rb16 = ((uint64_t)dim * dtype_size(data_type) + 15) / 16 * 16;
+  const uint64_t rem = rb16 % 128;
+  long on = 1, max_mb = 64;
+  if (const char* env = getenv("FLATNAV_SPLIT_ROWS")) on = strtol(env, nullptr, 10);
+  if (const char* env = getenv("FLATNAV_SPLIT_TAIL_MAX_MB")) max_mb = strtol(env, nullptr, 10);
+  if (on && rb16 - rem == 384 && rem > 0 && rem <= 32 && capacity * rem <= ((uint64_t)max_mb << 20))
+    return RowLayout{384u, (uint32_t)rem};
+  return RowLayout{row_stride_bytes(dim, data_type), 0u};
 }
 
 uint32_t pow2_ceil(uint64_t v) {
@@ -441,9 +465,11 @@ int write_nodes_impl(fnv_index_s* ix, uint64_t first_node, uint64_t count_nodes,
     const uint64_t count = std::min(chunk_nodes, count_nodes - done);
     const uint64_t first = first_node + done;
     UP_TRY(hipMemcpy(d_stage, (const uint8_t*)aos_rows + done * node_size, count * node_size, hipMemcpyHostToDevice));
-    const uint64_t units = count * (word_ok ? ix->row_bytes / 4 : ix->row_bytes);
+    const uint32_t row_all = ix->row_bytes + ix->tail_bytes;  // bytes of a row over both tables
+    const uint64_t units = count * (word_ok ? row_all / 4 : row_all);
     hipLaunchKernelGGL(relayout_vectors_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, 0, d_stage,
-                       node_size, data_size, ix->row_bytes, first, count, ix->d_vectors, word_ok);
+                       node_size, data_size, ix->row_bytes, ix->tail_bytes, first, count, ix->d_vectors,
+                       const_cast<uint8_t*>(ix->tails()), word_ok);
     hipLaunchKernelGGL(relayout_links_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, d_stage,
                        node_size, data_size, ix->M, first, count, id_limit, ix->d_links, ix->d_labels, d_bad);
     UP_TRY(hipGetLastError());
@@ -490,7 +516,9 @@ int fnv_index_alloc(uint32_t M, uint64_t n_nodes, int data_type, int metric, uin
   ix->dim = dim;
   ix->n_nodes = n_nodes;
   ix->capacity = n_nodes;
-  ix->row_bytes = row_stride_bytes(dim, data_type);
+  const RowLayout lay = row_layout(dim, data_type, n_nodes);
+  ix->row_bytes = lay.row_bytes;
+  ix->tail_bytes = lay.tail_bytes;
   rc = alloc_buffers(ix);
   if (rc) {
     fnv_index_free(ix);
@@ -540,6 +568,7 @@ int fnv_index_view(fnv_index_t src, fnv_index_t* out) {
   v->M = src->M;
   v->dim = src->dim;
   v->row_bytes = src->row_bytes;
+  v->tail_bytes = src->tail_bytes;
   v->n_nodes = src->n_nodes.load();
   v->capacity = src->capacity;
   v->d_vectors = src->d_vectors;
@@ -577,7 +606,9 @@ int fnv_index_adopt(const void* vectors, const void* links, const void* labels, 
   v->metric = metric;
   v->M = M;
   v->dim = dim;
-  v->row_bytes = row_stride_bytes(dim, data_type);
+  const RowLayout lay = row_layout(dim, data_type, n_nodes);  // (the owner's layout: same dim, type and capacity)
+  v->row_bytes = lay.row_bytes;
+  v->tail_bytes = lay.tail_bytes;
   v->n_nodes = n_nodes;
   v->capacity = n_nodes;
   v->d_vectors = (uint8_t*)const_cast<void*>(vectors);
@@ -602,7 +633,7 @@ int fnv_index_device_buffers(fnv_index_t ix, void* ptrs[3], uint64_t sizes[3]) {
   ptrs[0] = ix->d_vectors;
   ptrs[1] = ix->d_links;
   ptrs[2] = ix->d_labels;
-  sizes[0] = ix->capacity * (uint64_t)ix->row_bytes;
+  sizes[0] = ix->vector_bytes();  // (split rows: the main table, then the side table)
   sizes[1] = ix->capacity * (uint64_t)ix->M * 4;
   sizes[2] = ix->capacity * 4;
   return FNV_OK;
@@ -612,12 +643,12 @@ int fnv_index_info(fnv_index_t ix, uint64_t info[8]) {
   if (!ix || !info) return fail(FNV_ERR_INVALID, "null argument");
   info[0] = (uint64_t)ix->dtype;
   info[1] = ix->M;
-  info[2] = ix->row_bytes;
+  info[2] = (uint64_t)ix->row_bytes | ((uint64_t)ix->tail_bytes << 32);
   info[3] = ix->parent ? ix->parent->n_nodes.load() : ix->n_nodes.load();
   info[4] = ix->dim;
   info[5] = (uint64_t)ix->metric;
   info[6] = (uint64_t)ix->device;
-  info[7] = ix->capacity * ((uint64_t)ix->row_bytes + 4ull * ix->M + 4) + ix->bitmap_bytes + ix->spill_bytes;
+  info[7] = ix->capacity * ((uint64_t)ix->row_bytes + ix->tail_bytes + 4ull * ix->M + 4) + ix->bitmap_bytes + ix->spill_bytes;
   return FNV_OK;
 }
 
@@ -1057,6 +1088,8 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     SearchParams p;
     memset(&p, 0, sizeof(p));
     p.vectors = ix->d_vectors;
+    p.tails = ix->tails();
+    p.tail_chunks = ix->tail_bytes / 16;
     p.links = ix->d_links;
     p.M = ix->M;
     p.dim = ix->dim;
@@ -1064,9 +1097,10 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     p.nchunks = ix->row_bytes / 16;
     p.K = K;
     p.B = B;
-    const int cfg = pick_row_cfg(p.nchunks);
+    const int cfg = pick_row_cfg(p.nchunks, p.tail_chunks);
     const uint32_t per_iter = (uint32_t)(kCfgs[cfg].G * kCfgs[cfg].CU);
     p.q_chunks = (p.nchunks + per_iter - 1) / per_iter * per_iter;
+    if (p.tail_chunks) p.q_chunks = p.nchunks + (uint32_t)kCfgs[cfg].G;  // split rows: lane g also reads query chunk 24 + g (zero past the row)
     p.q_lds_bytes = cfg_query_in_regs(cfg) ? 0u : p.q_chunks * 16u;
     p.cand_slots = ix->cand_slots ? (uint32_t)ix->cand_slots : (uint32_t)(ix->cand_factor * p.B + 192);
     p.cand_slots = std::max<uint32_t>(p.cand_slots, (uint32_t)p.B + 1);  // also hosts the final result list
@@ -1075,7 +1109,8 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
     p.ovf_cap = ix->overflow_list >= 0 ? (uint32_t)ix->overflow_list
                                        : ((uint64_t)p.bitmap_words * 4 > (512u << 10) ? 16384u : 0u);
     p.log_entries = log_entries_for(ix, p.B);
-    const bool full = (p.nchunks % per_iter) == 0;  // rows are whole spans: the lean FULL kernels apply
+    const bool full = p.tail_chunks == 0 && (p.nchunks % per_iter) == 0;  // rows are whole spans: the lean FULL kernels apply
+                                                                            // (the three-line configuration's non-FULL form IS the split-row kernel)
     plan.cfg = cfg;
     plan.full = full;
 
@@ -1302,7 +1337,7 @@ static int search_device_impl(fnv_index_t ix, const void* d_queries, uint64_t nq
 
   HIP_TRY(hipMemsetAsync(ix->d_dispenser, 0, 16 * sizeof(uint32_t), stream));
   HIP_TRY(hipEventRecord(ix->ev0, stream));
-  if (ix->entry_kernel) {
+  if (ix->entry_kernel && !ix->tail_bytes) {  // (split rows: K0's LDS tiles hold one table's rows; the in-kernel scan serves them)
     // K0: one pass over the shared entry-scan nodes for the whole batch (LDS-staged), same stream
     rc = grow((void**)&ix->d_entry, &ix->entry_bytes, (size_t)nq * 8);
     if (rc) return rc;
@@ -1667,11 +1702,11 @@ int fnv_replica_refresh(fnv_index_t src, int n_replicas, fnv_index_t* replicas) 
     ~Restore() { if (dev >= 0) (void)hipSetDevice(dev); }
   } restore{caller_device};
   const uint64_t live = src->n_nodes;
-  const size_t bytes[3] = {(size_t)live * src->row_bytes, (size_t)live * src->M * 4, (size_t)live * 4};
+  const size_t bytes[4] = {(size_t)live * src->row_bytes, (size_t)live * src->M * 4, (size_t)live * 4, (size_t)live * src->tail_bytes};
   for (int i = 0; i < n_replicas; i++) {
     fnv_index_t r = replicas[i];
-    if (!r || r->capacity < live || r->row_bytes != src->row_bytes || r->M != src->M || r->dtype != src->dtype ||
-        r->metric != src->metric)
+    if (!r || r->capacity < live || r->row_bytes != src->row_bytes || r->tail_bytes != src->tail_bytes || r->M != src->M ||
+        r->dtype != src->dtype || r->metric != src->metric)
       return fail(FNV_ERR_INVALID, "fnv_replica_refresh: replica geometry does not match the source index");
   }
   // A replica answers its shard of a batch exactly as the source would: same options (kernel choice, node ids vs
@@ -1704,10 +1739,11 @@ int fnv_replica_refresh(fnv_index_t src, int n_replicas, fnv_index_t* replicas) 
     std::vector<fnv_index_t> round;
     for (size_t s = 0; s < senders && next < need.size(); s++, next++) {
       fnv_index_t from = have[s], to = need[next];
-      const void* srcp[3] = {from->d_vectors, from->d_links, from->d_labels};
-      void* dstp[3] = {to->d_vectors, to->d_links, to->d_labels};
+      const void* srcp[4] = {from->d_vectors, from->d_links, from->d_labels, from->tails()};
+      void* dstp[4] = {to->d_vectors, to->d_links, to->d_labels, const_cast<uint8_t*>(to->tails())};
       HIP_TRY(hipSetDevice(to->device));
-      for (int b = 0; b < 3; b++) {
+      for (int b = 0; b < 4; b++) {
+        if (bytes[b] == 0) continue;  // (no side table)
         if (from->device == to->device)
           HIP_TRY(hipMemcpyAsync(dstp[b], srcp[b], bytes[b], hipMemcpyDeviceToDevice, to->stream));
         else
@@ -1994,11 +2030,11 @@ int fnv_gather_ceiling(fnv_index_t ix, int waves_per_cu, double* gbps_out) {
   ON_DEVICE(ix->device);
   const uint64_t n_rows = ix->parent ? ix->parent->n_nodes.load() : ix->n_nodes.load();
   const uint32_t nchunks = ix->row_bytes / 16;
-  const int cfg = pick_row_cfg(nchunks);
+  const int cfg = pick_row_cfg(nchunks, ix->tail_bytes / 16);
   typedef void (*gather_fn)(const uint8_t*, uint64_t, uint32_t, int, uint32_t*);
   static const gather_fn kGather[kNumCfgs] = {gather_ceiling_kernel<8, 1>,  gather_ceiling_kernel<8, 2>,  gather_ceiling_kernel<8, 4>,
                                               gather_ceiling_kernel<16, 4>, gather_ceiling_kernel<32, 4>, gather_ceiling_kernel<64, 4>,
-                                              gather_ceiling_kernel<64, 3>};
+                                              gather_ceiling_kernel<64, 3>, gather_ceiling_kernel<8, 3>};  // (split rows: the main table's lines)
   const int G = kCfgs[cfg].G, CU = kCfgs[cfg].CU;
   const int PU = passes_of(G, CU);
   const int wpc = waves_per_cu > 0 ? std::min(waves_per_cu, 32) : 16;
@@ -2078,8 +2114,17 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
   }
   uint8_t* o = (uint8_t*)ix->d_out;
   // the new nodes' vectors are the queries (Index.h:371: beamSearch(data, entry, ef_construction)); dense rows
-  HIP_TRY(hipMemcpy2DAsync(ix->d_q, qrow, ix->d_vectors + first_node * (uint64_t)ix->row_bytes, ix->row_bytes, qrow,
-                           count, hipMemcpyDeviceToDevice, ix->stream));
+  if (!ix->tail_bytes) {
+    HIP_TRY(hipMemcpy2DAsync(ix->d_q, qrow, ix->d_vectors + first_node * (uint64_t)ix->row_bytes, ix->row_bytes, qrow,
+                             count, hipMemcpyDeviceToDevice, ix->stream));
+  } else {  // split rows: the main table's part of every row, then what the side table holds of it
+    const size_t main_part = std::min<size_t>(qrow, ix->row_bytes), tail_part = qrow - main_part;
+    HIP_TRY(hipMemcpy2DAsync(ix->d_q, qrow, ix->d_vectors + first_node * (uint64_t)ix->row_bytes, ix->row_bytes, main_part,
+                             count, hipMemcpyDeviceToDevice, ix->stream));
+    if (tail_part)
+      HIP_TRY(hipMemcpy2DAsync((uint8_t*)ix->d_q + main_part, qrow, ix->tails() + first_node * (uint64_t)ix->tail_bytes,
+                               ix->tail_bytes, tail_part, count, hipMemcpyDeviceToDevice, ix->stream));
+  }
   int rc = search_device_impl(ix, ix->d_q, count, W, W, num_initializations, (float*)(o + o_dist), (int32_t*)(o + o_lab),
                               (int32_t*)(o + o_cnt), (uint64_t*)(o + o_nd), nullptr, ix->stream, /*node_ids=*/true);
   if (rc) return rc;
@@ -2094,6 +2139,8 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
   uint32_t* sorted_req = (uint32_t*)(wb + 3 * req_bytes);
   void* sort_tmp = wb + 4 * req_bytes;
   w.vectors = ix->d_vectors;
+  w.tails = ix->tails();
+  w.tail_chunks = ix->tail_bytes / 16;
   w.links = ix->d_links;
   w.req_target = req_target;
   w.sorted_target = sorted_target;
@@ -2109,10 +2156,11 @@ int fnv_index_insert_batch(fnv_index_t ix, uint64_t first_node, uint64_t count, 
   w.keep = keep;
   w.row_bytes = ix->row_bytes;
   w.nchunks = ix->row_bytes / 16;
-  const int cfg = pick_row_cfg(w.nchunks);
+  const int cfg = pick_row_cfg(w.nchunks, w.tail_chunks);
   const uint32_t per_iter = (uint32_t)(kCfgs[cfg].G * kCfgs[cfg].CU);
   w.q_chunks = (w.nchunks + per_iter - 1) / per_iter * per_iter;
-  const bool full = (w.nchunks % per_iter) == 0;
+  if (w.tail_chunks) w.q_chunks = w.nchunks + (uint32_t)kCfgs[cfg].G;
+  const bool full = w.tail_chunks == 0 && (w.nchunks % per_iter) == 0;
   w.cap = std::max<uint32_t>((uint32_t)W, 4 * ix->M);  // connect prunes row + up to cap - M requesters at a time
   auto align16 = [](uint32_t v) { return (v + 15u) & ~15u; };
   uint32_t off = 0;

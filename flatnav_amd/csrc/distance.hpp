@@ -126,13 +126,33 @@ template <int G, int CU>
 constexpr bool query_in_regs() {
   return G == 64 && CU == 3;  // (the host picks this row configuration only for rows of exactly G * CU chunks)
 }
+// ---------------------------------------------------------------------------------------------
+// SPLIT ROWS (round 6).  A 100-d float32 row is 400 bytes: three whole 128-byte lines and 16 bytes.  At a 512-byte stride
+// (rounds 2-5) every gather fetched a fourth line of which 7/8 is padding -- 22 % of the HBM traffic of that configuration was
+// zeros (profiles/r5_pmc_hbm_traffic.json: 1.22 x the algorithmic bytes).  Split: the MAIN table holds the whole lines of
+// every row (stride 384), the last one or two chunks live in a dense side table of 16 / 32 bytes per row (1.18 M rows: 19 MB --
+// resident in L2 / Infinity Cache, so the fourth request per vector no longer goes to HBM).  Chunk c of a row is still
+// multiplied with chunk c of the query by the same lane as before (lane g of the vector's group: chunks g, g + 8, g + 16 from
+// the main table, then chunk 24 + g from the side table), so every distance keeps its bits.  One row configuration has the
+// form: G = 8, CU = 3 with FULL = false  (FULL = true is the plain 384-byte row: d = 96 float32 / 384 one-byte elements).
+// The host picks it for rows of 3 lines + at most 32 bytes whose side table stays small (beam_search.hip row_layout).
+// ---------------------------------------------------------------------------------------------
+template <int G, int CU, bool FULL>
+constexpr bool row_has_tail() {
+  return G == 8 && CU == 3 && !FULL;
+}
+
 template <int G, int CU>
 struct Query {
   const uint4* lds;                           // staged query; not read when the query lives in registers
+  const uint8_t* tails;                       // split rows: the side table (else unused)
+  uint32_t tail_chunks;                       // ... and its chunks per row
   uint4 r[query_in_regs<G, CU>() ? CU : 1];   // lane g: chunks g, g + G, ... of the query
   // registers from a query that has been staged in LDS (kernels that stage many different vectors: K0, wiring)
-  __device__ __forceinline__ void from_lds(const uint4* staged, int lane) {
+  __device__ __forceinline__ void from_lds(const uint4* staged, int lane, const uint8_t* tail_table = nullptr, uint32_t tail_chunks_ = 0u) {
     lds = staged;
+    tails = tail_table;
+    tail_chunks = tail_chunks_;
     if constexpr (query_in_regs<G, CU>()) {
 #pragma unroll
       for (int cu = 0; cu < CU; cu++) r[cu] = staged[cu * G + lane % G];
@@ -167,7 +187,35 @@ __device__ __forceinline__ void batch_dists(const uint8_t* rows, uint32_t row_st
     rowp[pu] = rows + (uint64_t)id[pu] * row_stride;
     acc[pu] = D::zero();
   }
-  if (FULL) {
+  if constexpr (row_has_tail<G, CU, FULL>()) {
+    // split rows (above): ONE span of G*CU chunks = the row's whole lines from the main table + up to G chunks from the side
+    // table, all issued before the first use; lanes without a tail chunk multiply zeros (the query is zero beyond the row)
+    const uint32_t tc = q.tail_chunks;
+    const bool has_tail = (uint32_t)g < tc;
+    uint4 y[PU][CU], yt[PU];
+#pragma unroll
+    for (int pu = 0; pu < PU; pu++) {
+      if (pu < npass) {
+#pragma unroll
+        for (int cu = 0; cu < CU; cu++) y[pu][cu] = *reinterpret_cast<const uint4*>(rowp[pu] + (g + cu * G) * 16);
+        yt[pu] = make_uint4(0u, 0u, 0u, 0u);
+        if (has_tail) yt[pu] = *reinterpret_cast<const uint4*>(q.tails + ((uint64_t)id[pu] * tc + (uint32_t)g) * 16u);
+      }
+    }
+#pragma unroll
+    for (int cu = 0; cu < CU; cu++) {
+      const uint4 x = q.lds[cu * G + g];
+      qacc = D::qchunk(qacc, x);
+#pragma unroll
+      for (int pu = 0; pu < PU; pu++)
+        if (pu < npass) acc[pu] = D::chunk(acc[pu], x, y[pu][cu]);
+    }
+    const uint4 xt = q.lds[G * CU + g];  // chunk 24 + g of the query: zero from the end of the row on (q_chunks = 32)
+    qacc = D::qchunk(qacc, xt);
+#pragma unroll
+    for (int pu = 0; pu < PU; pu++)
+      if (pu < npass) acc[pu] = D::chunk(acc[pu], xt, yt[pu]);
+  } else if (FULL) {
     // rows are a whole number of G*CU-chunk spans (e.g. d=128 f32: 32 chunks = 8 lanes x 4): no clamping, no
     // tail select; one address per pass, the CU loads use immediate offsets
 #pragma unroll

@@ -20,7 +20,7 @@ namespace fnv_dev {
 typedef FNV_INST_T T;
 constexpr int METRIC = FNV_INST_METRIC;
 
-// ROW(slot, kernel template, extra template arguments...) fills slot[cfg][full] for the six row configurations
+// ROW(slot, kernel template, extra template arguments...) fills slot[cfg][full] for the eight row configurations
 #define FNV_ROW(slot, K, ...)                                          \
   slot[0][FULL] = K<T, METRIC, 8, 1, FULL __VA_ARGS__>;                \
   slot[1][FULL] = K<T, METRIC, 8, 2, FULL __VA_ARGS__>;                \
@@ -28,7 +28,8 @@ constexpr int METRIC = FNV_INST_METRIC;
   slot[3][FULL] = K<T, METRIC, 16, 4, FULL __VA_ARGS__>;               \
   slot[4][FULL] = K<T, METRIC, 32, 4, FULL __VA_ARGS__>;               \
   slot[5][FULL] = K<T, METRIC, 64, 4, FULL __VA_ARGS__>;               \
-  slot[6][FULL] = K<T, METRIC, 64, 3, FULL __VA_ARGS__>;
+  slot[6][FULL] = K<T, METRIC, 64, 3, FULL __VA_ARGS__>;               \
+  slot[7][FULL] = K<T, METRIC, 8, 3, FULL __VA_ARGS__>;
 
 template <bool FULL>
 static void fill_rows(KernelTable& t) {

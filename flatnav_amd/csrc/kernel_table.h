@@ -16,15 +16,20 @@ typedef void (*wire_fn)(const WireParams);
 struct KernelCfg {
   int G, CU;
 };
-constexpr KernelCfg kCfgs[] = {{8, 1}, {8, 2}, {8, 4}, {16, 4}, {32, 4}, {64, 4}, {64, 3}};
-constexpr int kNumCfgs = 7;
+// ... and 24 for rows of three whole lines: FULL = plain 384-byte rows, non-FULL = SPLIT rows (three lines in the main table +
+// one or two chunks in the side table; distance.hpp row_has_tail)
+constexpr KernelCfg kCfgs[] = {{8, 1}, {8, 2}, {8, 4}, {16, 4}, {32, 4}, {64, 4}, {64, 3}, {8, 3}};
+constexpr int kNumCfgs = 8;
+constexpr int kCfgThreeLines = 7;
 
 // Row configuration for rows of `nchunks` 16-byte chunks: the narrowest one that covers the row in one span; longer
 // rows loop over 256-chunk spans.  Rows of exactly 192 chunks (768-d float32) have their own: every lane loads exactly
 // its three chunks, and the query lives in registers instead of LDS (distance.hpp, query_in_regs).
 inline bool cfg_query_in_regs(int cfg) { return kCfgs[cfg].G == 64 && kCfgs[cfg].CU == 3; }
-inline int pick_row_cfg(uint32_t nchunks) {
+inline int pick_row_cfg(uint32_t nchunks, uint32_t tail_chunks = 0) {
+  if (tail_chunks) return kCfgThreeLines;  // (the host splits rows of exactly 24 main chunks only)
   if (nchunks == 192) return 6;
+  if (nchunks == 24) return kCfgThreeLines;
   for (int c = 0; c < 6; c++)
     if ((uint32_t)(kCfgs[c].G * kCfgs[c].CU) >= nchunks) return c;
   return 5;

@@ -130,6 +130,8 @@ __device__ __forceinline__ void stage_query(Query<G, CU>& q, uint4* qlds, uint32
   const uint32_t dim = c->dim;
   const T* qsrc = reinterpret_cast<const T*>(c->queries) + (uint64_t)qi * dim;
   q.lds = qlds;
+  q.tails = c->tails;  // (split rows, distance.hpp; dead code in every other row configuration)
+  q.tail_chunks = c->tail_chunks;
   if constexpr (query_in_regs<G, CU>()) {
     constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
 #pragma unroll

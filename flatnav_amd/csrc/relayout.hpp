@@ -54,22 +54,27 @@ __global__ __launch_bounds__(WAVE) void heap_microbench_kernel(int size, int ite
 // a row are replaced by the node's own id (== already visited, see header comment).
 // ---------------------------------------------------------------------------------------------
 __global__ void relayout_vectors_kernel(const uint8_t* __restrict__ aos, uint64_t node_size, uint64_t data_size,
-                                        uint32_t row_bytes, uint64_t first_node, uint64_t count,
-                                        uint8_t* __restrict__ vectors, int word_ok) {
+                                        uint32_t row_bytes, uint32_t tail_bytes, uint64_t first_node, uint64_t count,
+                                        uint8_t* __restrict__ vectors, uint8_t* __restrict__ tails, int word_ok) {
+  // split rows (distance.hpp): bytes [0, row_bytes) of a row go to the main table, [row_bytes, row_bytes + tail_bytes) to the
+  // side table; zero from data_size on in either
   const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t row_all = row_bytes + tail_bytes;
   if (word_ok) {
-    const uint32_t wpr = row_bytes / 4;
+    const uint32_t wpr = row_all / 4;
     const uint64_t node = tid / wpr;
-    const uint32_t w = (uint32_t)(tid % wpr);
+    const uint32_t b = (uint32_t)(tid % wpr) * 4u;
     if (node >= count) return;
     uint32_t val = 0;
-    if ((uint64_t)w * 4 < data_size) val = *reinterpret_cast<const uint32_t*>(aos + node * node_size + (uint64_t)w * 4);
-    *reinterpret_cast<uint32_t*>(vectors + (first_node + node) * row_bytes + (uint64_t)w * 4) = val;
+    if ((uint64_t)b < data_size) val = *reinterpret_cast<const uint32_t*>(aos + node * node_size + b);
+    uint8_t* dst = b < row_bytes ? vectors + (first_node + node) * row_bytes + b : tails + (first_node + node) * tail_bytes + (b - row_bytes);
+    *reinterpret_cast<uint32_t*>(dst) = val;
   } else {
-    const uint64_t node = tid / row_bytes;
-    const uint32_t b = (uint32_t)(tid % row_bytes);
+    const uint64_t node = tid / row_all;
+    const uint32_t b = (uint32_t)(tid % row_all);
     if (node >= count) return;
-    vectors[(first_node + node) * row_bytes + b] = b < data_size ? aos[node * node_size + b] : (uint8_t)0;
+    uint8_t* dst = b < row_bytes ? vectors + (first_node + node) * row_bytes + b : tails + (first_node + node) * tail_bytes + (b - row_bytes);
+    *dst = b < data_size ? aos[node * node_size + b] : (uint8_t)0;
   }
 }
 

@@ -64,6 +64,8 @@ constexpr uint32_t STASH = 64;
 
 struct SearchParams {
   const uint8_t* vectors;   // [n_nodes][row_bytes]
+  const uint8_t* tails;     // split rows (round 6, distance.hpp): [n_nodes][tail_chunks * 16] -- the last chunks of every row, in a
+                            // dense side table, when that lets the main table hold whole 128-byte lines only; else null
   const uint32_t* links;    // [n_nodes][M]
   const int32_t* labels;    // [n_nodes]
   const uint8_t* queries;   // [nq][dim] elements, dense
@@ -87,7 +89,8 @@ struct SearchParams {
   uint32_t scan_tile_rows, scan_tile_stride;  // entry_scan_kernel: LDS tile geometry
   unsigned long long* phase_cycles;  // [16] profiling build only (FNV_PHASE_TIMING), else null
   uint64_t n_nodes;
-  uint32_t nq, M, dim, row_bytes, nchunks, q_chunks;
+  uint32_t nq, M, dim, row_bytes, nchunks, q_chunks;  // (split rows: row_bytes / nchunks describe the main table)
+  uint32_t tail_chunks;    // split rows: 16-byte chunks per row in `tails` (1 or 2), else 0
   uint32_t q_lds_bytes;    // LDS the staged query takes per slot: q_chunks * 16, or 0 when it lives in registers (distance.hpp)
   int K, B;
   uint32_t n_scan, scan_step;

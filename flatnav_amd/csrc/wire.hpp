@@ -32,6 +32,7 @@ namespace fnv_dev {
 
 struct WireParams {
   const uint8_t* vectors;  // [capacity][row_bytes]
+  const uint8_t* tails;    // split rows (distance.hpp): [capacity][tail_chunks * 16], else null
   uint32_t* links;         // [capacity][M]
   uint32_t* req_target;    // [count * keep] select: request r = i * keep + t (new node first_node + i) -> target node,
                            // EMPTY_ID for unused slots
@@ -41,15 +42,17 @@ struct WireParams {
   const int32_t* beam_ids; // [count][W] node ids
   const int32_t* beam_count;
   uint32_t* dispenser;
-  uint32_t first_node, count, W, M, keep, row_bytes, nchunks, q_chunks;
+  uint32_t first_node, count, W, M, keep, row_bytes, nchunks, q_chunks, tail_chunks;
   uint32_t cap;  // entries per LDS candidate array: max(W, 4 M)
   uint32_t off_q, off_ckey, off_cid, off_okey, off_oid, off_alive, off_kept, off_sel, off_stage_ids, off_stage_idx;
 };
 
-__device__ __forceinline__ void stage_vector(uint4* qlds, const uint8_t* vectors, uint32_t row_bytes, int nchunks,
-                                             uint32_t id, int lane) {
-  const uint4* src = reinterpret_cast<const uint4*>(vectors + (uint64_t)id * row_bytes);
+// Node `id`'s vector as the "query" of the distances that follow: its main-table chunks, then (split rows) its side-table chunks.
+__device__ __forceinline__ void stage_vector(uint4* qlds, const WireParams& p, uint32_t id, int lane) {
+  const uint4* src = reinterpret_cast<const uint4*>(p.vectors + (uint64_t)id * p.row_bytes);
+  const int nchunks = (int)p.nchunks;
   for (int c = lane; c < nchunks; c += WAVE) qlds[c] = src[c];
+  if ((uint32_t)lane < p.tail_chunks) qlds[nchunks + lane] = reinterpret_cast<const uint4*>(p.tails)[(uint64_t)id * p.tail_chunks + (uint32_t)lane];
   wave_sync();
 }
 
@@ -97,9 +100,9 @@ __device__ __forceinline__ int prune_ordered(const WireParams& p, uint4* qlds, c
     kept_n++;
     pos = found + 1;
     if (kept_n >= keep || pos >= C) break;
-    stage_vector(qlds, p.vectors, p.row_bytes, (int)p.nchunks, oid[found], lane);
+    stage_vector(qlds, p, oid[found], lane);
     Query<G, CU> q;
-    q.from_lds(qlds, lane);
+    q.from_lds(qlds, lane, p.tails, p.tail_chunks);
     for (int base = pos; base < C; base += WAVE) {
       const int j = base + lane;
       const bool a = j < C && alive[j] != 0u;
@@ -140,9 +143,9 @@ __device__ __forceinline__ void keys_from(const WireParams& p, uint4* qlds, uint
   constexpr int PU = passes<G, CU>();
   constexpr int VPW = WAVE / G;
   const int vgrp = lane / G;
-  stage_vector(qlds, p.vectors, p.row_bytes, (int)p.nchunks, base, lane);
+  stage_vector(qlds, p, base, lane);
   Query<G, CU> q;
-  q.from_lds(qlds, lane);
+  q.from_lds(qlds, lane, p.tails, p.tail_chunks);
   for (int b = 0; b < C; b += VPW * PU) {
     uint32_t id[PU];
     float d[PU];
@@ -196,7 +199,7 @@ __device__ __forceinline__ void pop_order(const float* okey_in, const uint32_t* 
   uint32_t* stage_ids = reinterpret_cast<uint32_t*>(smem + p.off_stage_ids);  \
   uint32_t* stage_idx = reinterpret_cast<uint32_t*>(smem + p.off_stage_idx);  \
   const int M = (int)p.M;                                                     \
-  for (uint32_t c = p.nchunks + lane; c < p.q_chunks; c += WAVE) qlds[c] = make_uint4(0u, 0u, 0u, 0u);
+  for (uint32_t c = p.nchunks + p.tail_chunks + lane; c < p.q_chunks; c += WAVE) qlds[c] = make_uint4(0u, 0u, 0u, 0u);
 
 template <typename T, int METRIC, int G, int CU, bool FULL>
 __global__ __launch_bounds__(WAVE, FNV_MIN_WAVES_PER_SIMD) void wire_select_kernel(const WireParams p) {

@@ -146,7 +146,8 @@ class DeviceIndex:
         check(lib().fnv_index_info(self._h, info))
         self.dtype = ORD_DTYPE[int(info[0])]
         self.M = int(info[1])
-        self.row_bytes = int(info[2])
+        self.row_bytes = int(info[2]) & 0xFFFFFFFF  # stride of the (main) vector table
+        self.tail_bytes = int(info[2]) >> 32        # split rows (csrc/distance.hpp): bytes per row in the side table that follows it
         self.n_nodes = int(info[3])
         self.dim = int(info[4])
         self.metric = "l2" if int(info[5]) == 0 else "angular"

@@ -74,13 +74,20 @@ def replicate_index(dev, device: int, src: int = 0, group=None, piece_bytes: int
     # broadcast the LIVE rows only: a device-built source may hold room for more nodes than it has, and the
     # replicas are allocated for the live count
     live = [dev.n_nodes * dev.row_bytes, dev.n_nodes * dev.M * 4, dev.n_nodes * 4]
-    views = []
-    for (ptr, nbytes), want in zip(dev.device_buffers(), live):
+    views, names = [], ["vectors", "links", "labels"]
+    bufs = dev.device_buffers()
+    for (ptr, nbytes), want in zip(bufs, live):
         if want > nbytes:
             raise RuntimeError("device buffer smaller than its live rows")
         views.append(torch.as_tensor(_DevView(ptr, want), device="cuda:%d" % device))
+    tail = getattr(dev, "tail_bytes", 0)
+    if tail:  # split rows: the side table follows the main table of THIS rank's capacity (csrc/beam_search.hip row_layout)
+        ptr, nbytes = bufs[0]
+        capacity = nbytes // (dev.row_bytes + tail)
+        views.append(torch.as_tensor(_DevView(ptr + capacity * dev.row_bytes, dev.n_nodes * tail), device="cuda:%d" % device))
+        names.append("vector tails")
     stats = broadcast_buffers(views, src=src, group=group, piece_bytes=piece_bytes, sync=lambda: torch.cuda.synchronize(device))
-    for name, st in zip(("vectors", "links", "labels"), stats):
+    for name, st in zip(names, stats):
         st["buffer"] = name
     return stats
 

@@ -110,10 +110,13 @@ int fnv_index_view(fnv_index_t src, fnv_index_t* out);
 int fnv_index_adopt(const void* vectors, const void* links, const void* labels, uint32_t M, uint64_t n_nodes,
                     int data_type, int metric, uint32_t dim, int device, fnv_index_t* out);
 
-/* Device pointers and byte sizes of the three index buffers: [0]=vectors [1]=links [2]=labels. */
+/* Device pointers and byte sizes of the three index buffers: [0]=vectors (split rows: table + side table) [1]=links [2]=labels. */
 int fnv_index_device_buffers(fnv_index_t index, void* ptrs[3], uint64_t sizes[3]);
 
-/* info[8] = {data_type, M, row_bytes, n_nodes, dim, metric, device, total_device_bytes}. */
+/* info[8] = {data_type, M, row_bytes | tail_bytes << 32, n_nodes, dim, metric, device, total_device_bytes}.
+ * row_bytes = stride of the vector table.  tail_bytes != 0 ("split rows", round 6): rows of three whole 128-byte lines plus at
+ * most 32 bytes (e.g. 100-d float32) keep their whole lines in the table (stride 384) and their last 16 / 32 bytes in a dense
+ * side table that FOLLOWS the table in the same buffer: row i's tail at vectors + capacity * row_bytes + i * tail_bytes. */
 int fnv_index_info(fnv_index_t index, uint64_t info[8]);
 
 int fnv_index_free(fnv_index_t index);

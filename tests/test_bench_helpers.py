@@ -68,7 +68,7 @@ def _full_entry(name, cpu=True, world=1):
                       "line_bytes_per_launch": 6415712345.5, "achieved_line_GBps": 6228.1, "avg_kernel_ms": 1.0301234,
                       "trace_position": {"timed": 20, "regions": 3, "after": 91}},
          "timed_regions": {"n": 3, "min": 9534766.1, "median": 9634766.123456789, "max": 9734766.9, "kernel_ms": [1.03, 1.031, 1.029], "note": "n" * 90},
-         "secondary": [], "sustained": {"value": 9.5e6}, "pipelined": {"value": 12034567.8, "note": "p" * 150},
+         "secondary": [], "sustained": {"value": 9.5e6, "seconds": 1.0123, "steps": 970, "unit": "queries/s", "note": "n" * 100}, "pipelined": {"value": 12034567.8, "note": "p" * 150},
          "single_query": {"ef_search": 1600, "calls": 200, "wall_ms_p50": 0.17234567, "wall_ms_p99": 0.189, "kernel_ms_p50": 0.13912345,
                           "value": 5780.123, "unit": "queries/s", "lds_bytes_per_slot": 130160, "note": "s" * 100}}
     if cpu:
@@ -91,14 +91,14 @@ def _record(names, world=1):
     return out
 
 
-def test_contract_line_of_a_seven_configuration_run_stays_under_4_kb():
+def test_contract_line_of_an_eight_configuration_run_stays_under_4_kb():
     # BENCH_r04.json: "parsed": null -- the one stdout line had grown to 25 KB.  Whatever the run holds, the line that goes to
     # stdout is at most 4 KB, parses, and carries roofline + cpu_baseline + one row per further configuration.
     names = bench.SECONDARY_DEFAULT[1].split(",")
-    assert len(names) == 6
+    assert len(names) == 7 and names[-1] == "c5-uint8"  # (the last one: the first to be skipped if the time budget runs out)
     out = _record(names)
     out["c5"] = {"skipped": "failed: MemoryError: " + "x" * 300}
-    out["secondary"][-2] = {"config": "c5", "skipped": True, "error": "MemoryError"}
+    out["secondary"][-3] = {"config": "c5", "skipped": True, "error": "MemoryError"}
     text = bench.contract_line(out, names, "c2", "bench_out/bench_full.json")
     assert len(text.encode()) < bench.CONTRACT_LINE_MAX and "\n" not in text
     d = json.loads(text)
@@ -112,6 +112,9 @@ def test_contract_line_of_a_seven_configuration_run_stays_under_4_kb():
     assert abs(r["traffic_over_algorithmic"] - 0.91) < 0.005 and r["avg_kernel_ms"] > 0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 16 and "100.00%" in d["cpu_baseline"]["sample"]
     assert d["value_pcie_inclusive"] == 8234567 and d["timed_regions"]["n"] == 3
+    #  the line itself says which rate `value` is and where SURVEY 8d's PCIe-inclusive one stands; the >= 1 s figure rides along
+    assert "value = device-resident rate" in d["config"]["workload"] and "8234567 queries/s = value_pcie_inclusive" in d["config"]["workload"]
+    assert d["sustained"] == {"value": 9.5e6, "seconds": 1.01, "steps": 970}
     assert d["single_query_ms"] == {"ef": 1600, "wall_p50": 0.172, "kernel_p50": 0.139}  # (one query per call: the reference's own protocol)
     rows = {row["config"]: row for row in d["secondary"] if row["config"] != "c2"}
     assert set(rows) == set(names) and "skipped" in rows["c5"] and rows["c4"]["frac"] == 0.779 and rows["c4"]["cpu"] > 0

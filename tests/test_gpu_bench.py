@@ -133,7 +133,8 @@ def test_bench_spawns_its_own_ranks_and_runs_other_configs(tmp_path):
     d, full = _run(cmd, tmp_path, env=env)
     assert d["n_gpus"] == 2 and d["config"]["workload"].startswith("c4 ") and d["value"] > 0
     assert d["roofline"]["frac_of_gather_ceiling"] > 0 and d["roofline"]["frac"] > 0  # (a 25 MB table gathers from L2: ceiling > HBM peak)
-    assert full["roofline"]["row_bytes"] == 400 and full["roofline"]["row_stride_bytes"] == 512  # 100-d rows on whole lines
+    # 100-d rows: three whole lines in the table + 16 bytes in the side table (split rows, round 6; rounds 2-5: a 512-byte stride)
+    assert full["roofline"]["row_bytes"] == 400 and full["roofline"]["row_stride_bytes"] == 384 and full["roofline"]["row_tail_bytes"] == 16
 
 
 @pytest.mark.parametrize("metric", ["l2", "angular"])

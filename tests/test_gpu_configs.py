@@ -125,7 +125,8 @@ def test_c5_shape_128d_randn_l2(oracle_mod, hipmod):
     _float_parity(oracle_mod, hipmod, ix, Q, 10, 100)
 
 
-@pytest.mark.parametrize("config,n_small,n_full", [("c3-lowrank", 400_000, 10_000_000), ("c5", 2_000_000, 50_000_000)])
+@pytest.mark.parametrize("config,n_small,n_full", [("c3-lowrank", 400_000, 10_000_000), ("c5", 2_000_000, 50_000_000),
+                                                   ("c5-uint8", 2_000_000, 50_000_000)])
 def test_fullsize_properties(oracle_mod, config, n_small, n_full):
     # Size-independent properties at the configurations' own sizes (see _fullsize), index built on the GPU from data
     # generated on the GPU: sortedness, exact recomputed distances for every returned id, idempotence across
@@ -140,18 +141,23 @@ def test_fullsize_properties(oracle_mod, config, n_small, n_full):
     SUMMARY_LINES.append("test_fullsize_properties[%s]: N = %d x %d -- %s" % (config, N, 768 if config == "c3-lowrank" else 128,
                                                                             "FULL SIZE" if full else "REDUCED (box too small or FNV_FULLSIZE=0)"))
     dim, metric, ef = (768, "angular", 200) if config == "c3-lowrank" else (128, "l2", 100)
+    dt = "uint8" if config == "c5-uint8" else "float32"  # c5-uint8 (round 6): an INTEGER dataset at HBM scale -- bit-exact ids
     NQ, K, M = 2000, 10, 32
     g = torch.Generator(device="cuda")
-    g.manual_seed(7712 if config == "c3-lowrank" else 50)
+    g.manual_seed(7712 if config == "c3-lowrank" else 1296 if config == "c5-uint8" else 50)
     W = torch.randn((32, dim), generator=g, device="cuda") / 32 ** 0.5
+    W16 = torch.randn((16, dim), generator=g, device="cuda") / 4
 
     def gen(m):
         if config == "c5":
             return torch.randn((m, dim), generator=g, device="cuda")
+        if config == "c5-uint8":  # SURVEY 8d's S1 generator (bench.py Data._gen), stored as bytes
+            x = 64 + 32 * (torch.randn((m, 16), generator=g, device="cuda") @ W16) + 6 * torch.randn((m, dim), generator=g, device="cuda")
+            return torch.clip(torch.round(x), 0, 255).to(torch.uint8)
         x = torch.randn((m, 32), generator=g, device="cuda") @ W + 0.05 * torch.randn((m, dim), generator=g, device="cuda")
         return x / x.norm(dim=1, keepdim=True)
 
-    ix = flatnav.index.create(metric, dim, N, M)
+    ix = flatnav.index.create(metric, dim, N, M, getattr(flatnav.data_type.DataType, dt))
     ix.set_num_threads(min(16, os.cpu_count() or 1))
     chunk = 1_000_000 if dim > 256 else 5_000_000
     for first in range(0, N, chunk):
@@ -162,6 +168,21 @@ def test_fullsize_properties(oracle_mod, config, n_small, n_full):
     d2, l2 = ix.search(Q, K, ef)
     assert np.array_equal(d, d2) and np.array_equal(l, l2)
     blob = np.asarray(ix._raw_blob()).reshape(N, ix._node_size_bytes)
+    if dt == "uint8":  # integer data: every returned distance is THE integer, ids / distances / counters equal the oracle's bits
+        rows = blob[l.reshape(-1), :dim].astype(np.int64).reshape(NQ, K, dim)
+        assert np.array_equal(((rows - Q[:, None, :].astype(np.int64)) ** 2).sum(-1).astype(np.float32), d)
+        import ctypes
+
+        from flatnav_amd import hip
+
+        dev = hip.DeviceIndex(ctypes.c_void_p(ix.device_handle()), owned=False)
+        gd, gl, gst = dev.search(Q, K, ef, stats=True)  # a full-grid launch (2000 queries, a shadow-free multi-slot one)
+        o = oracle_mod.OracleIndex.from_blob(metric, dt, dim, N, N, M, blob.reshape(-1))
+        od, ol, ost = o.search(Q[:1000], K, ef, threads=min(16, os.cpu_count() or 1), stats=True)
+        assert np.array_equal(gl, l) and np.array_equal(ol, l[:1000]) and np.array_equal(od.view(np.uint32), d[:1000].view(np.uint32))
+        assert np.array_equal(gst["n_dist"][:1000], ost["n_dist"]) and np.array_equal(gst["n_hops"][:1000], ost["n_hops"])
+        SUMMARY_LINES.append("test_fullsize_properties[%s]: ids, distance bits, n_dist, n_hops == oracle on 1000 of 1000 queries at N = %d (uint8)" % (config, N))
+        return
     rows = blob[l.reshape(-1), : dim * 4].copy().view(np.float32).reshape(NQ, K, dim)
     exact = ((rows - Q[:, None, :]) ** 2).sum(-1) if metric == "l2" else 1.0 - (rows * Q[:, None, :]).sum(-1)
     assert np.allclose(exact, d, rtol=1e-4, atol=1e-5)

@@ -29,7 +29,10 @@ def _upload(hipmod, ix):
 
 
 @pytest.mark.parametrize("dt,dim,metric", [("float32", 100, "angular"), ("uint8", 100, "l2"), ("float32", 200, "l2"),
-                                           ("int8", 37, "angular"), ("float32", 760, "l2")])
+                                           ("int8", 37, "angular"), ("float32", 760, "l2"),
+                                           # round 6, SPLIT ROWS (three whole lines + a 16 / 32-byte tail in a side table):
+                                           ("float32", 104, "l2"), ("float32", 97, "l2"), ("uint8", 400, "l2"), ("int8", 410, "angular"),
+                                           ("float32", 96, "angular"), ("uint8", 384, "l2")])  # ... and plain three-line rows
 def test_rows_on_whole_lines_keep_every_bit(oracle_mod, hipmod, dt, dim, metric, monkeypatch):
     rng = np.random.default_rng(dim)
     N, NQ = 6000, 400
@@ -48,24 +51,45 @@ def test_rows_on_whole_lines_keep_every_bit(oracle_mod, hipmod, dt, dim, metric,
     esize = 4 if dt == "float32" else 1
     rb16 = (dim * esize + 15) // 16 * 16
     rb128 = (rb16 + 127) // 128 * 128
+    monkeypatch.setenv("FLATNAV_SPLIT_ROWS", "0")  # (the padding rules of rounds 2-5 first)
     monkeypatch.setenv("FLATNAV_ROW_PAD_PCT", "0")
     plain = _upload(hipmod, ix)
-    assert plain.row_bytes == rb16
+    assert plain.row_bytes == rb16 and plain.tail_bytes == 0
     monkeypatch.delenv("FLATNAV_ROW_PAD_PCT")
     padded = _upload(hipmod, ix)
-    assert padded.row_bytes == (rb128 if (rb128 - rb16) * 100 <= 30 * rb16 else rb16)
+    assert padded.row_bytes == (rb128 if (rb128 - rb16) * 100 <= 30 * rb16 else rb16) and padded.tail_bytes == 0
     monkeypatch.setenv("FLATNAV_ROW_PAD_PCT", "400")
     always = _upload(hipmod, ix)
     assert always.row_bytes == rb128
-    cfg = [pick_cfg(dev.row_bytes // 16) for dev in (plain, padded, always)]
+    monkeypatch.delenv("FLATNAV_ROW_PAD_PCT")
+    monkeypatch.delenv("FLATNAV_SPLIT_ROWS")
+    layouts = [plain, padded, always]
+    rem = rb16 % 128
+    splits = rb16 - rem == 384 and 0 < rem <= 32  # csrc/beam_search.hip row_layout (the side table of 6000 rows is tiny)
+    default = _upload(hipmod, ix)  # what a caller gets
+    if splits:
+        assert default.row_bytes == 384 and default.tail_bytes == rem
+        assert default.device_buffers()[0][1] == N * (384 + rem)
+        layouts.append(default)
+        monkeypatch.setenv("FLATNAV_SPLIT_TAIL_MAX_MB", "0")  # a side table that would not stay cached: rows are padded instead
+        assert _upload(hipmod, ix).tail_bytes == 0
+        monkeypatch.delenv("FLATNAV_SPLIT_TAIL_MAX_MB")
+    else:
+        assert default.row_bytes == padded.row_bytes and default.tail_bytes == 0
+    # (split rows keep the lane-to-chunk mapping of the four-line padded row -- lane g: chunks g, g + 8, g + 16, g + 24 -- but not
+    #  that of the 16-byte stride's clamped path)
+    cfg = [pick_cfg(dev.row_bytes // 16, dev.tail_bytes // 16) for dev in layouts]
     for ef in (30, 150):
         for mode in (2, 0):
             outs = []
-            for dev in (plain, padded, always):
+            for dev in layouts:
                 dev.set_option("sorted_beam", mode)
                 outs.append(dev.search(Q, 10, ef, stats=True))
-            for i in (1, 2):
+            for i in range(1, len(layouts)):
                 other = outs[i]
+                if i == 3:  # split rows == the padded four-line row, bit for bit, floats included
+                    assert np.array_equal(outs[1][0].view(np.uint32), other[0].view(np.uint32)) and np.array_equal(outs[1][1], other[1])
+                    assert all(np.array_equal(outs[1][2][k], other[2][k]) for k in ("count", "n_dist", "n_hops"))
                 if dt != "float32" or cfg[i] == cfg[0]:
                     # integer arithmetic, or the same lane-to-chunk mapping (the zero padding adds nothing to either
                     # partial sum): the same bits
@@ -77,15 +101,17 @@ def test_rows_on_whole_lines_keep_every_bit(oracle_mod, hipmod, dt, dim, metric,
                     assert same.mean() >= 0.999 and np.allclose(outs[0][0][same], other[0][same], rtol=1e-5, atol=1e-6)
     if dt != "float32":  # integer data: also bit-exact against the oracle in every layout
         od, ol, ost = ix.search(Q, 10, 150, stats=True)
-        for dev in (plain, padded, always):
+        for dev in layouts:
             gd, gl, gst = dev.search(Q, 10, 150, stats=True)
             assert np.array_equal(ol, gl) and np.array_equal(od.view(np.uint32), gd.view(np.uint32))
             assert np.array_equal(ost["n_dist"], gst["n_dist"])
 
 
-def pick_cfg(nchunks):
+def pick_cfg(nchunks, tail_chunks=0):
     """csrc/kernel_table.h pick_row_cfg."""
     cfgs = [8, 16, 32, 64, 128, 256]
+    if tail_chunks or nchunks == 24:  # three whole lines (+ a side-table tail: split rows, round 6)
+        return 7
     if nchunks == 192:  # rows of exactly 3 KB: every lane loads its three chunks, the query lives in registers (round 4)
         return 6
     for c, span in enumerate(cfgs):

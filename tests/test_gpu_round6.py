@@ -81,3 +81,103 @@ def test_replicas_inherit_the_sources_measurements(oracle_mod):
     src.refresh_replicas(reps)
     got = hip.search_multi([src] + reps, Q, 10, 100, stats=True)
     assert np.array_equal(got[1], want100[1]) and all(np.array_equal(got[2][k], want100[2][k]) for k in ("n_dist", "n_hops"))
+
+
+# ---- SPLIT ROWS (csrc/distance.hpp, beam_search.hip row_layout): three whole lines in the table + the last 16 / 32 bytes of every
+#      row in a dense side table.  Search parity over the dims that split: tests/test_gpu_round3.py::test_rows_on_whole_lines_keep_every_bit.
+SPLIT_CASES = [("l2", "float32", 100), ("angular", "float32", 104), ("l2", "uint8", 400), ("angular", "int8", 410), ("l2", "float32", 97)]
+
+
+@pytest.mark.parametrize("metric,dt,dim", SPLIT_CASES, ids=["%s-%s-%d" % c for c in SPLIT_CASES])
+def test_split_rows_device_builder_reproduces_the_oracle_graph(flatnav, oracle_mod, metric, dt, dim):
+    # the device builder on split rows: the new nodes' vectors become queries (two strided copies), the wiring kernels stage a
+    # node's vector from both tables -- ONE node per batch must reproduce the oracle's single-threaded graph byte for byte
+    # (reference Index.h:353-378, 714-834), and the batched builder's graph must answer like the oracle searching it
+    import ctypes
+
+    from flatnav_amd import hip
+
+    rng = np.random.default_rng(dim)
+    N, M, efc = 1500, 8, 40
+    lo, hi = (-6, 6) if dt == "int8" else (0, 12)
+    X = rng.integers(lo, hi, (N, dim)).astype(dt)
+    Q = rng.integers(lo, hi, (300, dim)).astype(dt)
+    o = oracle_mod.OracleIndex.create(metric, dim, N, M, dt)
+    o.add(X, efc)
+    ix = flatnav.index.create(metric, dim, N, M, getattr(flatnav.data_type.DataType, dt))
+    ix.add(X, efc, device=True, device_max_batch=1, device_bootstrap=40)
+    dev = hip.DeviceIndex(ctypes.c_void_p(ix.device_handle()), owned=False)
+    assert dev.row_bytes == 384 and dev.tail_bytes in (16, 32)
+    want = np.asarray(o.blob())[: N * o.node_size].reshape(N, o.node_size)
+    got = np.asarray(ix._raw_blob())[: N * o.node_size].reshape(N, o.node_size)
+    bad = np.flatnonzero((want != got).any(axis=1))
+    assert bad.size == 0, "first differing node %d of %d differing" % (bad[0], bad.size)
+    for K, ef in ((10, 64), (1, 8), (20, 300)):  # beams in registers (one / two chunks) and in LDS
+        od, ol, ost = o.search(Q, K, ef, stats=True)
+        gd, gl, gst = dev.search(Q, K, ef, stats=True)
+        assert np.array_equal(gl, ol) and np.array_equal(gd.view(np.uint32), od.view(np.uint32)), (K, ef)
+        assert np.array_equal(gst["n_dist"], ost["n_dist"]) and np.array_equal(gst["n_hops"], ost["n_hops"])
+    dev.set_option("sorted_beam", 0)  # the two-heap kernel
+    gd, gl = dev.search(Q, 10, 64)
+    od, ol = o.search(Q, 10, 64)
+    assert np.array_equal(gl, ol) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+    dev.set_option("sorted_beam", 2)
+    dev.set_option("entry_kernel", 1)  # K0 holds one table's rows in its LDS tiles: ignored on split rows, same answers
+    gd, gl = dev.search(Q, 10, 64)
+    assert np.array_equal(gl, ol) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+    # batched insertion (the bench's builder): a valid graph that GPU and oracle search identically
+    big = flatnav.index.create(metric, dim, 6000, 16, getattr(flatnav.data_type.DataType, dt))
+    Xb = rng.integers(lo, hi, (6000, dim)).astype(dt)
+    big.add(Xb[:3500], 48, device=True)
+    big.add(Xb[3500:], 48, labels=list(range(3500, 6000)), device=True)  # the index grows: later rows of both tables
+    ob = oracle_mod.OracleIndex.from_blob("l2" if metric == "l2" else "ip", dt, dim, 6000, 6000, 16, np.asarray(big._raw_blob()))
+    od, ol = ob.search(Q, 10, 80)
+    gd, gl = big.search(Q, 10, 80)
+    assert np.array_equal(gl, ol) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+
+
+def test_split_rows_incremental_writes_views_adoption_and_replicas(oracle_mod):
+    from flatnav_amd import hip
+
+    rng = np.random.default_rng(100)
+    N, NQ, M, K, dim = 8000, 400, 16, 10, 100
+    X = rng.integers(0, 30, (N, dim)).astype(np.float32)
+    Q = rng.integers(0, 30, (NQ, dim)).astype(np.float32)
+    o = oracle_mod.OracleIndex.create("l2", dim, N, M, "float32")
+    o.add(X[: N // 2], 64)
+    blob = np.asarray(o.blob())
+    node_size, data_size, half = dim * 4 + 4 * M + 4, dim * 4, N // 2
+    want = o.search(Q, K, 80, stats=True)
+    whole = hip.DeviceIndex.upload(blob, node_size, data_size, M, half, "float32", "l2", dim)
+    inc = hip.DeviceIndex.alloc(M, N, "float32", "l2", dim)  # room for N, holds N / 2: its side table starts at N * 384
+    assert whole.tail_bytes == inc.tail_bytes == 16 and whole.row_bytes == inc.row_bytes == 384
+    inc.write_nodes(0, blob[: 1234 * node_size], node_size, data_size)
+    inc.write_nodes(1234, blob[1234 * node_size: half * node_size], node_size, data_size)
+    inc.set_live_nodes(half)
+    for dev in (whole, inc):
+        got = dev.search(Q, K, 80, stats=True)
+        assert np.array_equal(got[1], want[1]) and np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
+        assert np.array_equal(got[2]["n_dist"], want[2]["n_dist"])
+    view = inc.view()
+    guest = hip.DeviceIndex.adopt(inc.device_buffers(), M, N, "float32", "l2", dim, keep_alive=inc)  # (capacity N: the owner's layout)
+    guest.set_live_nodes(half)
+    assert guest.tail_bytes == 16
+    for dev in (view, guest):
+        got = dev.search(Q, K, 80)
+        assert np.array_equal(got[1], want[1]) and np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
+    view.close()
+    guest.close()
+    # replicas: both tables travel (the live rows of each), a refresh after growth as well
+    reps = whole.replicate([0, 0])
+    got = hip.search_multi([whole] + reps, Q, K, 80, stats=True)
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
+    grown = inc.replicate([0])
+    o.add(X[N // 2:], 64)
+    blob2 = np.asarray(o.blob())
+    inc.write_nodes(0, blob2, node_size, data_size)  # (links of old nodes changed too)
+    inc.set_live_nodes(N)
+    inc.refresh_replicas(grown)
+    want2 = o.search(Q, K, 80)
+    for dev in (inc, grown[0]):
+        got = dev.search(Q, K, 80)
+        assert np.array_equal(got[1], want2[1]) and np.array_equal(got[0].view(np.uint32), want2[0].view(np.uint32))
