@@ -10,8 +10,8 @@ import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 O = os.path.join(ROOT, "gpurun_out", "profile_set")
 P = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
-CONFIGS = ["c2", "c2-uint8", "c4", "c3-lowrank", "c3", "c5", "c5-lowrank"]
+tag = sys.argv[1] if len(sys.argv) > 1 else "r6"
+CONFIGS = ["c2", "c2-uint8", "c4", "c3-lowrank", "c3", "c5", "c5-lowrank", "c5-uint8"]
 
 
 def find(d, suffix):
@@ -125,8 +125,9 @@ for c in CONFIGS:
         r = fj["roofline"]
         corrected = (2 * F + W) * 1024
         traffic.append({
-            "config": c.replace("-uint8", ""), "dtype": "uint8" if c.endswith("uint8") else "float32",
-            "n": int(fj["config"]["index_bytes_in_hbm"] // (r["row_stride_bytes"] + 132)), "nq": 10000, "ef": fj["config"]["ef_search"], "kernel": meta,
+            # (bench.recorded_traffic's key: the 1M uint8 index is recorded as config c2 / dtype uint8, every other one under its own name)
+            "config": "c2" if c == "c2-uint8" else c, "dtype": "uint8" if c.endswith("uint8") else "float32",
+            "n": int(fj["config"]["index_bytes_in_hbm"] // (r["row_stride_bytes"] + r.get("row_tail_bytes", 0) + 132)), "nq": 10000, "ef": fj["config"]["ef_search"], "kernel": meta,
             "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --config %s --ef %d "
                        "--no-cpu-baseline --no-secondary --sustain-seconds 0 --warmup 3 --regions 1 --steps 3" % (c, fj["config"]["ef_search"]),
             "FETCH_SIZE_KB_per_launch": F, "WRITE_SIZE_KB_per_launch": W,
