@@ -1925,6 +1925,9 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
     // (6144 slots at 8 queries per CU: 3.06 ms against the rules' 3072 slots at 12 per CU: 3.74 ms; profiles/r5_table_sizes_50m.txt)
     // (only where tags are wide: with 16-bit tags every size has the same format and the neighbours above suffice)
     const uint32_t up2 = ix->plan.sorted.vis_w != 16u ? base_slots * 2 : 0u;  // 3 * 2^j -> 3 * 2^(j+1): the same tag format
+    // (two sizes DOWN was measured in round 6 and is not a candidate: on 50M x 128 uint8 -- 128-byte rows, 12 resident queries
+    //  per CU -- 1536 slots keep 18-20 queries resident and are 32-48 % SLOWER than 3072 slots at 12: what a smaller table sends
+    //  to the HBM bitmap costs more than the queries in flight it buys; profiles/r6_table_sizes_50m_uint8.txt)
     for (uint32_t slots : {up, down, up2}) {
       if (slots < 256 || slots > (1u << 15)) continue;
       fnv_index_s::LayoutChoice c;
@@ -2284,6 +2287,22 @@ int fnv_debug_phase_cycles(fnv_index_t ix, uint64_t out[16]) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out, ix->d_phase, NPHASE * sizeof(uint64_t), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemset(ix->d_phase, 0, NPHASE * sizeof(uint64_t)));
+  return FNV_OK;
+}
+#endif
+
+#ifdef FNV_SPEC_STATS
+// Developer builds only (-DFNV_SPEC_STATS): {hops whose node was the runner-up guessed one hop ahead, hops} of the last launch's
+// queries that finished in the merged-beam kernel.
+int fnv_debug_spec_stats(fnv_index_t ix, uint64_t out[2]) {
+  if (!ix || !out) return fail(FNV_ERR_INVALID, "null argument");
+  ix = last_launcher(ix);
+  ON_DEVICE(ix->device);
+  HIP_TRY(hipStreamSynchronize(ix->last_stream));
+  uint32_t w[2];
+  HIP_TRY(hipMemcpy(w, ix->d_dispenser + 11, sizeof(w), hipMemcpyDeviceToHost));
+  out[0] = w[0];
+  out[1] = w[1];
   return FNV_OK;
 }
 #endif

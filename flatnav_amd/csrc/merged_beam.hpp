@@ -215,7 +215,15 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : R == MB_R ? 3 : waves_per_simd<
     int spec_node = -1;
     uint32_t spec_row = EMPTY_ID;
     auto load_row = [&](const int nd) -> uint32_t { return lane < M ? links[(uint64_t)(uint32_t)nd * (uint32_t)M + lane] : EMPTY_ID; };
+#ifdef FNV_SPEC_STATS  // developer build (tools/dev/spec_guess_stats.py): how often the runner-up guessed one hop ahead IS the next node
+    uint32_t spec_hits = 0;
+    auto take_row = [&](const int nd) -> uint32_t {
+      spec_hits += nd == spec_node ? 1u : 0u;
+      return nd == spec_node ? spec_row : load_row(nd);
+    };
+#else
     auto take_row = [&](const int nd) -> uint32_t { return nd == spec_node ? spec_row : load_row(nd); };
+#endif
     // (not for 1-byte elements: their hop is bound by instruction issue, not by latency -- the guess bought the uint8 index
     // nothing and cost ~20 M scalar instructions per launch, 162 -> 143 M in profiles/r3_sq_counters.json)
     auto guess_next = [&](const int nd, const int runner_up) {
@@ -640,6 +648,10 @@ __global__ __launch_bounds__(WAVE, CU == 1 ? 5 : R == MB_R ? 3 : waves_per_simd<
       }
       if (lane == 0) {
         if (c->out_count) c->out_count[qi] = cnt;
+#ifdef FNV_SPEC_STATS
+        atomicAdd(c->redo_count + 8, spec_hits);
+        atomicAdd(c->redo_count + 9, n_hops);
+#endif
 #ifdef FNV_TIMELINE
         if (c->out_ndist) c->out_ndist[qi] = tl_start;
         if (c->out_nhops) c->out_nhops[qi] = wall_clock64();

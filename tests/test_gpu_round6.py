@@ -181,3 +181,45 @@ def test_split_rows_incremental_writes_views_adoption_and_replicas(oracle_mod):
     for dev in (inc, grown[0]):
         got = dev.search(Q, K, 80)
         assert np.array_equal(got[1], want2[1]) and np.array_equal(got[0].view(np.uint32), want2[0].view(np.uint32))
+
+
+def test_advice_r5_option_bounds_and_launch_records_from_the_serving_lane(oracle_mod):
+    # "tie_log_entries" is bounded (it sizes max_slots x entries x 8 bytes of workspace); after concurrent callers
+    # -- some served by hidden lanes -- the handle's "most recent launch" records (replayed queries, hand-over statistics,
+    # kernel time) all describe ONE launch: the one of the lane that served last
+    import threading
+
+    from flatnav_amd import hip
+
+    X, Q = ds.sift_like(20000, 6000)
+    Xu, Qu = X.astype(np.uint8), Q.astype(np.uint8)
+    o = oracle_mod.OracleIndex.create("l2", 128, 20000, 32, "uint8")
+    o.add(Xu, 64)
+    dev = hip.DeviceIndex.upload(o.blob(), o.node_size, o.data_size, o.M, o.cur_nodes, "uint8", "l2", 128)
+    with pytest.raises(ValueError):
+        dev.set_option("tie_log_entries", (1 << 20) + 1)
+    dev.set_option("tie_log_entries", 1 << 20)  # the largest allowed: 8 MB per slot -- a small launch still fits
+    want = o.search(Qu, 10, 52, stats=True, threads=8)
+    got = dev.search(Qu[:64], 10, 52, stats=True)
+    assert np.array_equal(got[1], want[1][:64]) and np.array_equal(got[2]["n_dist"], want[2]["n_dist"][:64])
+    dev.set_option("tie_log_entries", 0)
+    dev.set_option("sorted_beam", 1)
+    dev.set_option("sorted_variant", 1)  # every query through the merged-beam kernel: tied ones are handed over
+    outs = [None] * 4
+
+    def work(t):
+        for rep in range(3):
+            outs[t] = dev.search(Qu[t * 1500:(t + 1) * 1500], 10, 52, stats=True)
+
+    for _ in range(3):
+        th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        for t in range(4):
+            assert np.array_equal(outs[t][1], want[1][t * 1500:(t + 1) * 1500])
+            assert np.array_equal(outs[t][0].view(np.uint32), want[0][t * 1500:(t + 1) * 1500].view(np.uint32))
+            assert np.array_equal(outs[t][2]["n_hops"], want[2]["n_hops"][t * 1500:(t + 1) * 1500])
+        r, h = dev.replayed_queries(), dev.handover_stats()
+        assert h["resumed"] + h["from_scratch"] == r["total"], (r, h)  # (both from the same launch)
+        assert dev.last_kernel_ms() > 0
+    assert sum(1 for w in hip.lane_workspaces(dev)[1:] if w) >= 1  # (lanes really served)
