@@ -488,7 +488,7 @@ int write_nodes_impl(fnv_index_s* ix, uint64_t first_node, uint64_t count_nodes,
 extern "C" {
 
 const char* fnv_last_error(void) { return g_err.c_str(); }
-const char* fnv_version(void) { return "flatnav_hip gfx950 r5"; }
+const char* fnv_version(void) { return "flatnav_hip gfx950 r6"; }
 
 int fnv_device_count(int* count) {
   if (!count) return fail(FNV_ERR_INVALID, "count is null");
@@ -1992,17 +1992,19 @@ int fnv_tune(fnv_index_t ix, const void* queries, uint64_t nq, int queries_on_de
       // 2 % (round 5 saw layouts that were 2-2.5 % faster on every box stay unused: 10M x 768 at 8192 slots).
       float sum_b = 0.f, sum_c = 0.f;
       bool wins = true;
-      for (int round = 0; round < 2 && wins; round++) {
+      int rounds = 0;
+      for (; rounds < 2 && wins; rounds++) {
         float tb = -1.f, tc = -1.f;
         if (time_layout(best_layout, &tb) != FNV_OK || time_layout(li, &tc) != FNV_OK) wins = false;
         else wins = tc < tb * 0.99f;
         sum_b += tb;
         sum_c += tc;
       }
-      if (tune_log) fprintf(stderr, "fnv_tune B=%d duel: layout %zu %.4f ms against layout %zu %.4f ms -> %s\n", B, li, sum_c / 2 * (float)nq,
-                            best_layout, sum_b / 2 * (float)nq, wins && sum_c < sum_b * 0.98f ? "challenger" : "holder");
+      if (tune_log) fprintf(stderr, "fnv_tune B=%d duel (%d round%s): layout %zu %.4f ms against layout %zu %.4f ms -> %s\n", B, rounds, rounds == 1 ? "" : "s",
+                            li, sum_c / (float)rounds * (float)nq, best_layout, sum_b / (float)rounds * (float)nq,
+                            wins && sum_c < sum_b * 0.98f ? "challenger" : "holder");
       if (wins && sum_c < sum_b * 0.98f) {
-        best_layout_t = sum_c / 2;
+        best_layout_t = sum_c / (float)rounds;
         best_layout = li;
         won_by_duel = true;
       }

@@ -266,7 +266,10 @@ int fnv_search_batch_device(fnv_index_t index, const void* d_queries, uint64_t n
  *   stream); free each with fnv_index_free.  One process drives all GPUs -- processes that own one GPU each
  *   (torch.distributed) broadcast the buffers of fnv_index_device_buffers with RCCL instead.
  * fnv_replica_refresh: copies the live rows of `src` into existing replicas again (after the source grew or was
- *   re-wired); replicas also take over the source's options (fnv_set_option) at every refresh.
+ *   re-wired); replicas also take over the source's options (fnv_set_option) at every refresh and -- round 6 -- what the
+ *   source has MEASURED (fnv_tune: kernel variant, LDS layout) when they sit on the same GPU model: tune the source, not
+ *   every replica.  A source tuned after its replicas were made hands the measurements over at the next
+ *   fnv_search_batch_multi whose indexes[0] it is (as long as its options are still the ones the replicas were given).
  * fnv_search_batch_multi: fnv_search_batch over several handles of the same index: rows [g*ceil(Q/G), ...) go to
  *   indexes[g]; every shard is driven by its own host thread (staging copies, launch and wait of all devices
  *   overlap), results land in the caller's row ranges.  The calling thread's current HIP device is left as it was
