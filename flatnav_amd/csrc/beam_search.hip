@@ -502,6 +502,16 @@ int fnv_device_count(int* count) {
   return FNV_OK;
 }
 
+int fnv_row_layout(uint32_t dim, int data_type, uint64_t capacity, uint32_t* row_bytes, uint32_t* tail_bytes) {
+  if (!row_bytes || !tail_bytes) return fail(FNV_ERR_INVALID, "null argument");
+  if (dtype_size(data_type) == 0) return fail(FNV_ERR_RUNTIME, "Unsupported data type");
+  if (dim == 0 || capacity == 0) return fail(FNV_ERR_INVALID, "dim and capacity must be positive");
+  const RowLayout lay = row_layout(dim, data_type, capacity);
+  *row_bytes = lay.row_bytes;
+  *tail_bytes = lay.tail_bytes;
+  return FNV_OK;
+}
+
 int fnv_index_alloc(uint32_t M, uint64_t n_nodes, int data_type, int metric, uint32_t dim, int device,
                     fnv_index_t* out) {
   if (!out) return fail(FNV_ERR_INVALID, "out is null");

@@ -26,7 +26,7 @@ C_ABI_SYMBOLS = [
     "fnv_index_set_live_nodes", "fnv_index_write_nodes", "fnv_index_write_links", "fnv_index_insert_batch",
     "fnv_index_read_links", "fnv_last_replayed_queries", "fnv_replicate", "fnv_replica_refresh",
     "fnv_search_batch_multi", "fnv_index_view", "fnv_tune", "fnv_last_launch_info", "fnv_gather_ceiling",
-    "fnv_index_adopt", "fnv_lane_info", "fnv_last_handover_stats",
+    "fnv_index_adopt", "fnv_lane_info", "fnv_last_handover_stats", "fnv_row_layout",
 ]
 
 _lib = None
@@ -58,6 +58,8 @@ def lib() -> C.CDLL:
                                   C.POINTER(C.c_void_p)]
     L.fnv_index_device_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.fnv_index_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    if hasattr(L, "fnv_row_layout"):  # (round 6; older builds under the A/B tools lack it)
+        L.fnv_row_layout.argtypes = [C.c_uint32, C.c_int, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.fnv_index_free.argtypes = [C.c_void_p]
     L.fnv_index_set_live_nodes.argtypes = [C.c_void_p, C.c_uint64]
     L.fnv_index_write_nodes.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]
@@ -101,6 +103,13 @@ def check(rc: int) -> None:
     if rc == FNV_ERR_NO_DEVICE:
         raise DeviceUnavailable(msg)
     raise RuntimeError(msg)
+
+
+def row_layout(dim: int, dtype: str, capacity: int):
+    """(row_bytes, tail_bytes) of the vector table the library keeps for this geometry (fnv_row_layout; needs no GPU)."""
+    rb, tb = C.c_uint32(0), C.c_uint32(0)
+    check(lib().fnv_row_layout(dim, DTYPE_ORD[dtype], capacity, C.byref(rb), C.byref(tb)))
+    return int(rb.value), int(tb.value)
 
 
 def device_count() -> int:

@@ -110,6 +110,14 @@ int fnv_index_view(fnv_index_t src, fnv_index_t* out);
 int fnv_index_adopt(const void* vectors, const void* links, const void* labels, uint32_t M, uint64_t n_nodes,
                     int data_type, int metric, uint32_t dim, int device, fnv_index_t* out);
 
+/* How the library lays out the vector table of an index of this geometry, without a handle and without a GPU (round 6): what a
+ * caller that fills buffers for fnv_index_adopt itself has to know.  *row_bytes = stride of the table (16-byte chunks, whole
+ * 128-byte lines when that pads <= 30 %: FLATNAV_ROW_PAD_PCT); *tail_bytes != 0: split rows -- the table holds the row's three whole
+ * lines, the last 16 / 32 bytes of row i live at vectors + capacity * row_bytes + i * tail_bytes (FLATNAV_SPLIT_ROWS,
+ * FLATNAV_SPLIT_TAIL_MAX_MB; see fnv_index_info).  The vectors buffer is capacity * (row_bytes + tail_bytes) bytes, zero beyond
+ * each row's dim elements.  (No reference interface: the reference's layout is the AoS node record, Index.h:61-63, 555-573.) */
+int fnv_row_layout(uint32_t dim, int data_type, uint64_t capacity, uint32_t* row_bytes, uint32_t* tail_bytes);
+
 /* Device pointers and byte sizes of the three index buffers: [0]=vectors (split rows: table + side table) [1]=links [2]=labels. */
 int fnv_index_device_buffers(fnv_index_t index, void* ptrs[3], uint64_t sizes[3]);
 

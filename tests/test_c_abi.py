@@ -76,6 +76,36 @@ def test_argument_validation_needs_no_device(libpath):
     assert b"index is null" in L.fnv_last_error()
 
 
+def test_row_layout_rules_need_no_device(libpath, monkeypatch):
+    # fnv_row_layout: the stride / split-row rule of the vector table (csrc/beam_search.hip row_layout), a pure function of
+    # (dim, element type, capacity) and three environment variables
+    from flatnav_amd import hip
+
+    for k in ("FLATNAV_ROW_PAD_PCT", "FLATNAV_SPLIT_ROWS", "FLATNAV_SPLIT_TAIL_MAX_MB"):
+        monkeypatch.delenv(k, raising=False)
+    assert hip.row_layout(128, "float32", 10**6) == (512, 0)      # whole lines already
+    assert hip.row_layout(128, "uint8", 10**6) == (128, 0)
+    assert hip.row_layout(768, "float32", 10**7) == (3072, 0)
+    assert hip.row_layout(100, "float32", 1_183_514) == (384, 16)  # GloVe shape: three lines + a 16-byte tail in the side table
+    assert hip.row_layout(104, "float32", 1000) == (384, 32) and hip.row_layout(97, "float32", 1000) == (384, 16)
+    assert hip.row_layout(400, "uint8", 1000) == (384, 16) and hip.row_layout(410, "int8", 1000) == (384, 32)
+    assert hip.row_layout(96, "float32", 1000) == (384, 0)         # exactly three lines: nothing to split
+    assert hip.row_layout(105, "float32", 1000) == (512, 0)        # 48 bytes over: padded (<= 30 %), not split
+    assert hip.row_layout(200, "float32", 1000) == (896, 0)        # six lines + 32 bytes: the kernels split three-line rows only
+    assert hip.row_layout(37, "int8", 1000) == (48, 0)             # padding to a line would cost 167 %: 16-byte stride
+    assert hip.row_layout(100, "float32", 5_000_000) == (512, 0)   # an 80 MB side table would not stay cached: padded
+    monkeypatch.setenv("FLATNAV_SPLIT_TAIL_MAX_MB", "128")
+    assert hip.row_layout(100, "float32", 5_000_000) == (384, 16)
+    monkeypatch.setenv("FLATNAV_SPLIT_ROWS", "0")
+    assert hip.row_layout(100, "float32", 1000) == (512, 0)
+    monkeypatch.setenv("FLATNAV_ROW_PAD_PCT", "0")
+    assert hip.row_layout(100, "float32", 1000) == (400, 0)
+    with pytest.raises(RuntimeError):  # "Unsupported data type" (reference bindings.cpp:498-499): uint64 is not an index element type
+        hip.check(hip.lib().fnv_row_layout(100, 3, 10, C.byref(C.c_uint32()), C.byref(C.c_uint32())))
+    with pytest.raises(ValueError):
+        hip.row_layout(100, "float32", 0)
+
+
 def test_search_without_gpu_fails_loudly():
     import numpy as np
     import torch
