@@ -105,8 +105,9 @@ int fnv_index_view(fnv_index_t src, fnv_index_t* out);
  * them ([n_nodes][row_bytes] vectors at the library's row stride, see fnv_index_info[2]; [n_nodes][M] uint32 links;
  * [n_nodes] int32 labels), all on `device`: e.g. buffers that another process shares over HIP IPC, that a collective
  * filled inside a framework's allocation, or that another build of this library uploaded (tools/dev/knob_sweep.py A/Bs
- * library builds on one copy of a 32 GB index this way).  The handle has its own workspace, stream and options and never
- * frees the buffers; there is no reference interface for this (the reference's index lives in one process's heap). */
+ * library builds on one copy of a 32 GB index this way).  `n_nodes` is the CAPACITY the buffers were laid out for: with split
+ * rows (fnv_row_layout) the side table starts at vectors + n_nodes * row_bytes; fewer live nodes: fnv_index_set_live_nodes.
+ * The handle has its own workspace, stream and options and never frees the buffers; there is no reference interface for this (the reference's index lives in one process's heap). */
 int fnv_index_adopt(const void* vectors, const void* links, const void* labels, uint32_t M, uint64_t n_nodes,
                     int data_type, int metric, uint32_t dim, int device, fnv_index_t* out);
 
