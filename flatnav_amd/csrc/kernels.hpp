@@ -558,7 +558,10 @@ __device__ __forceinline__ void exact_query(const ExactCtx& x, const Query<G, CU
       if (c->out_count) c->out_count[qi] = err ? 0 : cnt;
       if (c->out_ndist) c->out_ndist[qi] = n_dist;
       if (c->out_nhops) c->out_nhops[qi] = n_hops;
-      if (err) atomicMax(c->status, err);
+      if (err) {
+        atomicMax(c->status, err);
+        if (c->host_status) __hip_atomic_store(c->host_status, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (every writer stores the same code)
+      }
     }
   }
   PH_MARK(7);

@@ -79,6 +79,7 @@ struct SearchParams {
                             // [1..4] by reason, [5] of them resumed from their log, [6] hops taken from the logs,
                             // [7] hops the merged-beam passes of the resumed queries had made
   int32_t* status;          // sticky error flag for the whole launch
+  int32_t* host_status;     // (round 6, zero-copy small searches) the same flag in the caller's pinned result slab, or null
   uint32_t* ovf_bitmap;     // [nslots][bitmap_words] visited-set spill (all zero between queries)
   uint32_t* ovf_glist;      // [nslots][ovf_cap] ids sent to the bitmap beyond the first OVF_LIST (big indexes only)
   unsigned long long* cand_spill;  // [nslots][spill_entries]

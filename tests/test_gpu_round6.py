@@ -223,3 +223,64 @@ def test_advice_r5_option_bounds_and_launch_records_from_the_serving_lane(oracle
         assert h["resumed"] + h["from_scratch"] == r["total"], (r, h)  # (both from the same launch)
         assert dev.last_kernel_ms() > 0
     assert sum(1 for w in hip.lane_workspaces(dev)[1:] if w) >= 1  # (lanes really served)
+
+
+def test_zero_copy_host_searches_change_no_byte(oracle_mod):
+    # "host_zero_copy" (default: on for every call that fits the pinned staging buffer): the kernel reads the queries from pinned
+    # host memory and writes results, counters and the error flag straight into it.  The oracle's bytes with it and without it,
+    # from 1 to 1500 queries (beyond the buffer the call copies as before), K > results (fewer than K reachable: -1 / inf
+    # padding and the count), concurrent callers on hidden lanes, and the error flag: a candidate heap that overflows its
+    # spill area must still raise through the pinned copy of the flag.
+    import threading
+
+    from flatnav_amd import hip
+
+    X, Q = ds.sift_like(20000, 1500)
+    Xu, Qu = X.astype(np.uint8), Q.astype(np.uint8)
+    o = oracle_mod.OracleIndex.create("l2", 128, 20000, 32, "uint8")
+    o.add(Xu, 64)
+    dev = hip.DeviceIndex.upload(o.blob(), o.node_size, o.data_size, o.M, o.cur_nodes, "uint8", "l2", 128)
+    for K, ef in ((10, 52), (1, 8), (40, 300)):
+        want = o.search(Qu, K, ef, stats=True, threads=8)
+        for nq in (1, 3, 64, 700, 1500):
+            for zc in (1 << 20, 0, 2):  # 2: only the smallest batches
+                dev.set_option("host_zero_copy", zc)
+                got = dev.search(Qu[:nq], K, ef, stats=True)
+                what = "K=%d ef=%d %d queries host_zero_copy=%d" % (K, ef, nq, zc)
+                assert np.array_equal(got[1], want[1][:nq]) and np.array_equal(got[0].view(np.uint32), want[0][:nq].view(np.uint32)), what
+                assert all(np.array_equal(got[2][k], want[2][k][:nq]) for k in ("count", "n_dist", "n_hops")), what
+    dev.set_option("host_zero_copy", 1 << 20)
+    want = o.search(Qu, 10, 52, stats=True, threads=8)
+    outs, errs = [None] * 6, []
+
+    def work(t):
+        try:
+            for rep in range(20):
+                q0 = (t * 37 + rep * 11) % 1400
+                n = 1 + (t + rep) % 5
+                d, l = dev.search(Qu[q0:q0 + n], 10, 52)
+                assert np.array_equal(l, want[1][q0:q0 + n]) and np.array_equal(d.view(np.uint32), want[0][q0:q0 + n].view(np.uint32))
+        except Exception as exc:  # noqa: BLE001
+            errs.append(repr(exc))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    # fewer than K reachable results: a tiny graph, K larger than it
+    small = oracle_mod.OracleIndex.create("l2", 128, 40, 4, "uint8")
+    small.add(Xu[:40], 8)
+    ds_ = hip.DeviceIndex.upload(small.blob(), small.node_size, small.data_size, small.M, small.cur_nodes, "uint8", "l2", 128)
+    ws = small.search(Qu[:5], 60, 80, stats=True)
+    gs = ds_.search(Qu[:5], 60, 80, stats=True)
+    assert np.array_equal(gs[1], ws[1]) and np.array_equal(gs[2]["count"], ws[2]["count"]) and (gs[2]["count"] < 60).all()
+    # the error flag travels through the pinned slab: a candidate heap with no LDS home and a one-entry spill area overflows
+    # (the configuration tests/test_gpu_parity.py uses for the same error on a copied call)
+    dev.set_option("sorted_beam", 0)
+    dev.set_option("cand_slots", 8)
+    dev.set_option("spill_entries", 1)
+    with pytest.raises(RuntimeError, match="spill"):
+        dev.search(Qu[:100], 10, 100)
+    dev.set_option("host_zero_copy", 0)
+    with pytest.raises(RuntimeError, match="spill"):
+        dev.search(Qu[:100], 10, 100)
