@@ -381,6 +381,8 @@ def contract_line(out, names, main_name, full_path):
         line["cpu_baseline"] = {"value": _sig(cpu["value"], 6), "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"],
                                 "sample": cpu.get("sample_short") or cpu["sample"][:160]}
     line["value_pcie_inclusive"] = c.get("host_buffer_qps_pcie_inclusive")
+    if c.get("host_buffer_qps_pinned_caller_zero_copy"):
+        line["value_pcie_inclusive_pinned_caller"] = c["host_buffer_qps_pinned_caller_zero_copy"]  # (zero-copy: the caller's arrays are pinned)
     line["timed_regions"] = {k: (_sig(v) if not isinstance(v, list) else [_sig(x, 4) for x in v])
                              for k, v in (out.get("timed_regions") or {}).items() if k != "note"} or None
     if out.get("sustained"):  # >= 1 s of back-to-back steps: the timed region of the contract (--steps launches) is ~20 ms
@@ -420,7 +422,7 @@ def contract_line(out, names, main_name, full_path):
     line["full_record"] = full_path
     # what may go, in this order, if a line ever grows past the limit
     droppable = [("roofline", "traffic_over_algorithmic"), ("config", "launch"), ("config", "parallelism"), ("cpu_baseline", "sample"),
-                 (None, "single_query_ms"), (None, "two_launches_in_flight"), (None, "timed_regions"), (None, "multi_gpu"), (None, "sustained")]
+                 (None, "value_pcie_inclusive_pinned_caller"), (None, "single_query_ms"), (None, "two_launches_in_flight"), (None, "timed_regions"), (None, "multi_gpu"), (None, "sustained")]
     text = json.dumps(line, separators=(",", ":"))
     while len(text.encode()) > CONTRACT_LINE_MAX:
         if droppable:
@@ -550,7 +552,7 @@ def run_config(ctx, args, config, main_line):
 
     launches = {"n": 0, "timed_end": 0, "timed_open": False}
     launches_lock = threading.Lock()  # (the host entry point is also called from several threads below)
-    _sd, _sh = dev.search_device, dev.search
+    _sd, _sh, _si = dev.search_device, dev.search, dev.search_into
 
     def _count_device(*a, **k):
         with launches_lock:
@@ -562,7 +564,12 @@ def run_config(ctx, args, config, main_line):
             launches["n"] += 1
         return _sh(*a, **k)
 
-    dev.search_device, dev.search = _count_device, _count_host
+    def _count_into(*a, **k):
+        with launches_lock:
+            launches["n"] += 1
+        return _si(*a, **k)
+
+    dev.search_device, dev.search, dev.search_into = _count_device, _count_host, _count_into
     ROW = dev.row_bytes  # bytes one row occupies in HBM (>= DIM * ESIZE: 16-byte chunks, whole 128-byte lines when cheap)
     TAIL = getattr(dev, "tail_bytes", 0)  # split rows (round 6): the row's last chunks live in a small cache-resident side table
     # bytes of the 128-byte lines one row touches: the stride itself when rows are whole lines, else the expectation for
@@ -746,6 +753,20 @@ def run_config(ctx, args, config, main_line):
             dev.search(Q_rank[(i + 1) % nb], K, EF)
             host_ts.append(time.perf_counter() - t0)
         host_qps = NQ / float(np.median(host_ts))
+        # ... and for a caller whose arrays are pinned host memory (torch pin_memory): zero-copy at any batch size -- the kernel reads
+        # the queries from and writes the results into the caller's own memory (round 6)
+        qpin = torch.from_numpy(Q_rank[:min(nb, 8)]).pin_memory()
+        dpin, lpin = torch.empty((NQ, K), dtype=torch.float32).pin_memory(), torch.empty((NQ, K), dtype=torch.int32).pin_memory()
+        dev.search_into(qpin[0].numpy(), K, EF, dpin.numpy(), lpin.numpy())
+        pin_ts = []
+        for i in range(7):
+            t0 = time.perf_counter()
+            dev.search_into(qpin[(i + 1) % qpin.shape[0]].numpy(), K, EF, dpin.numpy(), lpin.numpy())
+            pin_ts.append(time.perf_counter() - t0)
+        host_pinned_qps = NQ / float(np.median(pin_ts))
+        _, l_check = dev.search(Q_rank[7 % qpin.shape[0]], K, EF)  # (the last batch searched above)
+        host_pinned_same = bool(np.array_equal(l_check, lpin.numpy()))
+        del qpin, dpin, lpin
         # ... and with two and four caller threads on the one handle (concurrent callers run on the handle's hidden lanes:
         # their copies and launches overlap -- the reference's search is callable from several threads at once)
         def callers(T, per):
@@ -762,7 +783,8 @@ def run_config(ctx, args, config, main_line):
         callers(4, 2)  # (first contention creates the lanes and their launch plans: outside the timed regions)
         host2_qps = callers(2, 8)
         host4_qps = callers(4, 8)
-        log("[rank 0] host-buffer (PCIe-inclusive) path: %.0f queries/s; two / four caller threads: %.0f / %.0f queries/s" % (host_qps, host2_qps, host4_qps))
+        log("[rank 0] host-buffer (PCIe-inclusive) path: %.0f queries/s; pinned caller arrays (zero-copy): %.0f queries/s (ids equal: %s); "
+            "two / four caller threads: %.0f / %.0f queries/s" % (host_qps, host_pinned_qps, host_pinned_same, host2_qps, host4_qps))
     # ---- two batches in flight (rank-local, informational): a second handle on the same HBM buffers (fnv_index_view),
     #      a second stream, launches alternate -- the drain of one launch (its last, slowest queries at falling
     #      occupancy) overlaps the start of the next.  This is the rate a server that always has the next batch ready
@@ -888,6 +910,8 @@ def run_config(ctx, args, config, main_line):
                 "exploratory_timed_launches": main_m["explored"],
                 "queries_replayed_by_exact_kernel": replay["total"],
                 "host_buffer_qps_pcie_inclusive": round(host_qps),
+                "host_buffer_qps_pinned_caller_zero_copy": round(host_pinned_qps),
+                "host_buffer_pinned_caller_ids_equal": host_pinned_same,
                 "host_buffer_qps_two_caller_threads": round(host2_qps),
                 "host_buffer_qps_four_caller_threads": round(host4_qps),
                 "index_bytes_in_hbm": index_bytes,
@@ -945,7 +969,7 @@ def run_config(ctx, args, config, main_line):
     if out is not None:
         out["roofline"]["trace_position"]["after"] = launches["n"] - launches["timed_end"]
     # ---- give everything back before the next configuration ----------------------------------------------------------
-    dev.search_device, dev.search = _sd, _sh
+    dev.search_device, dev.search, dev.search_into = _sd, _sh, _si
     dev.close()
     del dev, index, dq, d_dist, d_lab, d_cnt, d_nd, d_nh, gts, data, Q_all, Q_rank
     gc.collect()

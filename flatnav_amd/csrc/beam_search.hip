@@ -1473,6 +1473,34 @@ static int search_host_enqueue(fnv_index_t ix, const void* queries, uint64_t nq,
   const bool pinned_results = !pinned && ix->h_res && ((obytes + 63) & ~(size_t)63) + 64 <= ix->h_res_bytes;
   uint8_t* o = (uint8_t*)ix->d_out;
   ix->pin = PinnedCall();
+  // A caller whose arrays are ALREADY pinned (hipHostMalloc / hipHostRegister / torch pin_memory) needs no staging at any batch
+  // size (round 6): the kernel reads the queries from and writes the results into the caller's own memory -- each query
+  // crosses PCIe once while the launch runs, nothing is copied before or after it.  (Batches that fit the staging buffer take
+  // the path below whatever their memory is: one attribute query per array costs more than their copies.)
+  if (!pinned && ix->host_zero_copy != 0) {
+    auto device_view = [](const void* host) -> void* {
+      if (!host) return nullptr;
+      hipPointerAttribute_t a;
+      if (hipPointerGetAttributes(&a, host) != hipSuccess || a.type != hipMemoryTypeHost || !a.devicePointer) {
+        (void)hipGetLastError();  // (pageable memory is "invalid value" to the runtime)
+        return nullptr;
+      }
+      return a.devicePointer;
+    };
+    void* dq = device_view(queries);
+    void* dd = dq ? device_view(out_dist) : nullptr;
+    void* dl = dd ? device_view(out_labels) : nullptr;
+    void* dc = out_count ? device_view(out_count) : nullptr;
+    void* dn = out_ndist ? device_view(out_ndist) : nullptr;
+    void* dh = out_nhops ? device_view(out_nhops) : nullptr;
+    if (dq && dd && dl && (!out_count || dc) && (!out_ndist || dn) && (!out_nhops || dh)) {
+      int rc0 = search_device_impl(ix, dq, nq, K, ef_search, num_initializations, (float*)dd, (int32_t*)dl, (int32_t*)dc, (uint64_t*)dn,
+                                   (uint64_t*)dh, ix->stream, false, -1, /*ids_by_option=*/true);
+      if (rc0) return rc0;
+      ix->t_enqueue_ns = now_ns();
+      return FNV_OK;  // (search_host_finish: wait + the launch's status word)
+    }
+  }
   // ZERO-COPY (round 6, "host_zero_copy" = the largest batch that takes it; default: every call that fits the 1 MB pinned
   // staging buffer): the kernel reads the queries straight from the pinned buffer and writes results, counters and its error
   // flag straight into it -- three stream operations (one copy in, two out) fewer per call; each query is read over PCIe

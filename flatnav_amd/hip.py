@@ -284,6 +284,20 @@ class DeviceIndex:
             return d, l, {"count": cnt, "n_dist": nd, "n_hops": nh}
         return d, l
 
+    def search_into(self, queries: np.ndarray, K: int, ef_search: int, dist: np.ndarray, labels: np.ndarray,
+                    num_initializations: int = 100) -> None:
+        """Host-buffer batched search into arrays the CALLER owns (no allocation, no conversion): queries [Q, dim] of the index's
+        element type, dist float32 [Q, K], labels int32 [Q, K], all C-contiguous.  When all three are pinned host memory
+        (e.g. numpy views of torch tensors from pin_memory()) the call is zero-copy at any batch size."""
+        if (queries.dtype != _np_dtype(self.dtype) or queries.ndim != 2 or queries.shape[1] != self.dim or not queries.flags.c_contiguous):
+            raise ValueError("Queries have incorrect dimensions.")
+        nq = queries.shape[0]
+        if dist.shape != (nq, K) or labels.shape != (nq, K) or dist.dtype != np.float32 or labels.dtype != np.int32 \
+                or not dist.flags.c_contiguous or not labels.flags.c_contiguous:
+            raise ValueError("output arrays must be C-contiguous float32 / int32 [Q, K]")
+        check(lib().fnv_search_batch(self._h, queries.ctypes.data, nq, K, ef_search, num_initializations, dist.ctypes.data,
+                                     labels.ctypes.data, None, None, None))
+
     def search_device(self, q_ptr: int, nq: int, K: int, ef_search: int, num_initializations: int, dist_ptr: int,
                       label_ptr: int, count_ptr: int = 0, ndist_ptr: int = 0, nhops_ptr: int = 0,
                       stream: int = 0) -> None:

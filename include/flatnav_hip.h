@@ -218,7 +218,9 @@ int fnv_index_read_links(fnv_index_t index, uint64_t first_node, uint64_t count,
  *   "host_zero_copy"  (round 6; default 2^20 = every call that fits the handle's 1 MB pinned staging buffer) fnv_search_batch calls
  *                     of at most this many queries run zero-copy: the kernel reads the queries from the pinned buffer and
  *                     writes results, counters and its error flag straight into it -- three stream operations fewer per
- *                     call (one query at ef=50 on 1M x 128: 0.157 -> 0.143 ms wall).  0 = every call copies in and out.  Same bytes.
+ *                     call (one query at ef=50 on 1M x 128: 0.157 -> 0.143 ms wall).  Larger calls whose arrays (queries AND
+ *                     every output passed) are already pinned host memory -- hipHostMalloc, hipHostRegister, torch's
+ *                     pin_memory -- run zero-copy on the caller's own memory.  0 = every call copies in and out.  Same bytes.
  *   "tune_layout"     1 (default): fnv_tune also measures the LDS layout (see fnv_tune); 0 = kernel variants only
  *   "sorted_beam_min" smallest beam width the merged-beam kernel is used for (default 1)
  *   "sorted_cand_lds" where the exact re-run of the merged-beam kernel keeps its candidates heap: 2 (default) = in LDS

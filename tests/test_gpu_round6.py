@@ -284,3 +284,35 @@ def test_zero_copy_host_searches_change_no_byte(oracle_mod):
     dev.set_option("host_zero_copy", 0)
     with pytest.raises(RuntimeError, match="spill"):
         dev.search(Qu[:100], 10, 100)
+
+
+def test_callers_with_pinned_arrays_run_zero_copy_at_any_batch_size(oracle_mod):
+    # fnv_search_batch on arrays that are ALREADY pinned host memory (torch pin_memory): beyond the staging buffer's size the kernel
+    # reads the queries from and writes the results into the caller's own memory; mixed (pinned queries, pageable outputs) and
+    # pageable callers copy as before.  The oracle's bytes on every path.
+    import torch
+
+    from flatnav_amd import hip
+
+    X, Q = ds.sift_like(20000, 6000)  # 6000 x 512 bytes = 3 MB of queries: three times the staging buffer
+    o = oracle_mod.OracleIndex.create("l2", 128, 20000, 32)
+    o.add(X, 64)
+    dev = hip.DeviceIndex.upload(o.blob(), o.node_size, o.data_size, o.M, o.cur_nodes, "float32", "l2", 128)
+    want = o.search(Q, 10, 52, threads=8)
+    qpin = torch.from_numpy(Q).pin_memory()
+    dpin, lpin = torch.empty((6000, 10), dtype=torch.float32).pin_memory(), torch.empty((6000, 10), dtype=torch.int32).pin_memory()
+    for rep in range(3):
+        dpin.zero_(); lpin.zero_()
+        dev.search_into(qpin.numpy(), 10, 52, dpin.numpy(), lpin.numpy())
+        assert np.array_equal(lpin.numpy(), want[1]) and np.array_equal(dpin.numpy().view(np.uint32), want[0].view(np.uint32))
+    d2, l2 = np.empty((6000, 10), np.float32), np.empty((6000, 10), np.int32)  # pageable outputs: the call copies
+    dev.search_into(qpin.numpy(), 10, 52, d2, l2)
+    assert np.array_equal(l2, want[1]) and np.array_equal(d2.view(np.uint32), want[0].view(np.uint32))
+    dev.search_into(Q, 10, 52, dpin.numpy(), lpin.numpy())  # pageable queries, pinned outputs
+    assert np.array_equal(lpin.numpy(), want[1])
+    dev.set_option("host_zero_copy", 0)  # off: pinned callers copy too
+    dpin.zero_()
+    dev.search_into(qpin.numpy(), 10, 52, dpin.numpy(), lpin.numpy())
+    assert np.array_equal(lpin.numpy(), want[1]) and np.array_equal(dpin.numpy().view(np.uint32), want[0].view(np.uint32))
+    with pytest.raises(ValueError):
+        dev.search_into(qpin.numpy(), 10, 52, dpin.numpy()[:, :5], lpin.numpy())
